@@ -1,0 +1,33 @@
+"""Seeded synthetic inputs of the shapes the reference pipeline feeds the hot path.
+
+There are no datasets or MIDI files on the GPU box, so benchmarks, parity tests and
+golden vectors all draw from these numpy (PCG64) generators; the same seed gives the
+same array everywhere.  Shapes follow SURVEY.md 8(d) "Value distributions / seeds".
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def gaussian(shape, seed: int) -> np.ndarray:
+    return np.random.Generator(np.random.PCG64(seed)).standard_normal(tuple(shape)).astype(np.float32)
+
+
+def chords(batch: int, seed: int, n_step: int = 32) -> np.ndarray:
+    """[B, 32, 36]: one-hot root (12) | Bernoulli(0.3) chroma (12) | one-hot bass (12)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = np.zeros((batch, n_step, 36), np.float32)
+    root = rng.integers(0, 12, (batch, n_step))
+    bass = rng.integers(0, 12, (batch, n_step))
+    out[..., 12:24] = (rng.random((batch, n_step, 12)) < 0.3).astype(np.float32)
+    np.put_along_axis(out[..., 0:12], root[..., None], 1.0, axis=-1)
+    np.put_along_axis(out[..., 24:36], bass[..., None], 1.0, axis=-1)
+    return out
+
+
+def prmat(batch: int, seed: int, steps: int = 128, pitches: int = 128) -> np.ndarray:
+    """[B, 128, 128] sparse integer durations: Bernoulli(0.02) * U{1..16}."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    on = rng.random((batch, steps, pitches)) < 0.02
+    dur = rng.integers(1, 17, (batch, steps, pitches))
+    return (on * dur).astype(np.float32)
