@@ -1,0 +1,172 @@
+/* pfhip.h - C ABI of libpfhip.so: the MI355X (gfx950) denoising hot path of Polyffusion.
+ *
+ * The reference is pure Python/PyTorch and has no FFI for this path; its interface is the
+ * call signature of the denoiser and of the sampler step.  Each entry point
+ * below cites the reference callable it replaces (paths relative to
+ * /root/reference/polyffusion).  INTEGRATION.md shows the ctypes stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative PF_E* code on failure; the message
+ *     is available from pf_last_error() (thread-local).  No exceptions cross the ABI.
+ *   - all device buffers are owned by the caller (allocated e.g. through torch); the
+ *     library never allocates or frees device memory and never synchronises the device.
+ *   - kernels are enqueued on the caller's hipStream_t (passed as void*), so they order with
+ *     the caller's other work and can be captured into a hipGraph.
+ *   - activations at the ABI are fp32.  x / eps are NCHW [B,C,H,W] exactly as the reference
+ *     passes them; internal activations are NHWC and never leave the workspace.
+ */
+#ifndef PFHIP_H
+#define PFHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_OK 0
+#define PF_EINVAL (-1)   /* bad argument / unsupported shape */
+#define PF_ENOTFOUND (-2) /* unknown parameter key */
+#define PF_ESTATE (-3)   /* call order violated (e.g. forward before bind) */
+#define PF_EHIP (-4)     /* HIP runtime error */
+
+int pf_version(void);
+const char* pf_last_error(void);
+
+/* ---- denoiser (replaces UNetModel.__init__/forward, stable_diffusion/model/unet.py:30-196,
+ *      incl. SpatialTransformer, unet_attention.py:26-333) ---------------------------------- */
+typedef struct pf_unet pf_unet;
+
+typedef struct pf_unet_cfg {
+  int32_t in_channels, out_channels, channels, n_res_blocks;
+  int32_t n_attention_levels;
+  int32_t attention_levels[8];
+  int32_t n_levels;
+  int32_t channel_multipliers[8];
+  int32_t n_heads, tf_layers, d_cond;
+  int32_t img_h, img_w; /* spatial size of x (params.img_h/img_w) */
+} pf_unet_cfg;
+
+int pf_unet_create(const pf_unet_cfg* cfg, pf_unet** out);
+void pf_unet_destroy(pf_unet* u);
+
+/* Weight ingestion in the reference state_dict namespace (keys relative to ldm.eps_model.,
+ * SURVEY.md Appendix D; replaces nn.Module.load_state_dict for unet.py).  The caller owns a
+ * host staging blob of pf_unet_weight_bytes(); pf_unet_pack_param repacks ONE named tensor
+ * (fp32, contiguous, torch layout) into its kernel-friendly place inside that blob.
+ * pf_unet_pack_missing returns the number of keys not yet packed (0 = complete) and writes
+ * the first missing key into buf.  The packed blob is then copied to the device by the
+ * caller (or received by RCCL broadcast) and attached with pf_unet_bind_weights. */
+size_t pf_unet_weight_bytes(const pf_unet* u);
+int pf_unet_n_params(const pf_unet* u);
+int pf_unet_param_info(const pf_unet* u, int i, char* key_buf, size_t key_buf_len, int64_t shape[4], int* ndim);
+int pf_unet_pack_param(pf_unet* u, const char* key, const float* src, const int64_t* shape, int ndim, void* host_blob);
+int pf_unet_pack_missing(const pf_unet* u, char* buf, size_t buf_len);
+int pf_unet_bind_weights(pf_unet* u, const void* dev_blob);
+
+/* Workspace (activations, skips, statistics) for a given batch / number of context tokens. */
+size_t pf_unet_workspace_bytes(const pf_unet* u, int batch, int n_cond);
+
+/* eps = UNet(x, t, cond): x [B,Cin,H,W] f32, t [B] i64, cond [B,n_cond,d_cond] f32,
+ * eps [B,Cout,H,W] f32 (unet.py:171-196; LatentDiffusion.forward latent_diffusion.py:138-147). */
+int pf_unet_forward(pf_unet* u, const float* x, const int64_t* t, const float* cond, int batch, int n_cond,
+                    float* eps, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-launch profiling: when enabled, forward brackets every kernel launch with hipEvents
+ * on the launch stream.  pf_unet_profile_read synchronises those events and returns, per
+ * launch: a kernel-family id (PF_K_*), elapsed ms and the algorithmic FLOPs of the launch. */
+enum { PF_K_CONV3 = 0, PF_K_GEMM = 1, PF_K_ATTN = 2, PF_K_GNSTAT = 3, PF_K_LNSTAT = 4, PF_K_SMALL = 5, PF_K_COUNT = 6 };
+int pf_unet_set_profiling(pf_unet* u, int enabled);
+int pf_unet_profile_read(pf_unet* u, int* kind, float* ms, double* flops, int capacity);
+int pf_unet_n_launches(const pf_unet* u, int batch, int n_cond);
+
+/* ---- sampler steps (elementwise, NCHW fp32, n = B*C*H*W elements) -------------------------
+ * Classifier-free guidance combine (DiffusionSampler.get_eps, stable_diffusion/sampler/__init__.py:69-77):
+ *   eps = e_uncond + scale * (e_cond - e_uncond), where eps2 = [e_uncond ; e_cond] (2n elements). */
+int pf_cfg_combine(const float* eps2, float scale, float* eps, size_t n, void* stream);
+
+/* One DDPM RePaint iteration (SDFSampler.paint body + p_sample, sampler_sdf.py:80-171,307-336):
+ *   x0    = c_recip*x - c_recipm1*eps ; mean = c_x0*x0 + c_xt*x ; x_unkn = mean + sigma*noise_p
+ *   x_kn  = sqrt_ab*orig + sqrt_1mab*noise_q          (skipped when orig == NULL)
+ *   x_out = x_kn*mask + x_unkn*(1-mask)
+ * noise_p / noise_q may be NULL (treated as zero: step 0).  x_out may alias x. */
+typedef struct pf_ddpm_coef { float c_recip, c_recipm1, c_x0, c_xt, sigma, sqrt_ab, sqrt_1mab; } pf_ddpm_coef;
+int pf_ddpm_step(const float* x, const float* eps, const float* noise_p, const float* noise_q,
+                 const float* orig, const float* mask, const pf_ddpm_coef* c, float* x_out, size_t n, void* stream);
+
+/* RePaint re-noise between inner repeats (sampler_sdf.py:337-341; keeps the reference's beta-not-sqrt quirk):
+ *   x_t = a*x + b*noise */
+int pf_axpby(const float* x, const float* noise, float a, float b, float* out, size_t n, void* stream);
+
+/* One DDIM iteration (DDIMSampler.get_x_prev_and_pred_x0 + paint blend, sampler_ddim.py:220-272,355-359):
+ *   pred_x0 = (x - s1m*eps)/sqrt_a ; x_prev = sqrt_aprev*pred_x0 + dir_coef*eps + sigma*noise
+ *   if orig: x_prev = (q_sqrt_a*orig + q_s1m*orig_noise)*mask + x_prev*(1-mask) */
+typedef struct pf_ddim_coef { float s1m, sqrt_a, sqrt_aprev, dir_coef, sigma, q_sqrt_a, q_s1m; } pf_ddim_coef;
+int pf_ddim_step(const float* x, const float* eps, const float* noise, const float* orig, const float* orig_noise,
+                 const float* mask, const pf_ddim_coef* c, float* x_out, size_t n, void* stream);
+
+/* Standard-normal noise, counter-based (Philox4x32-10 + Box-Muller), keyed by (seed, stream_id,
+ * global element index) so results do not depend on how a batch is sharded over GPUs.
+ * elem_offset = index of out[0] in the global (unsharded) tensor. */
+int pf_randn(float* out, size_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, void* stream);
+
+/* ---- condition encoders (replace RnnEncoder.forward dl_modules/chord_enc.py:15-22 and
+ *      TextureEncoder.forward dl_modules/txt_enc.py:23-35; only the Normal's mean is produced) */
+typedef struct pf_encoder pf_encoder;
+enum { PF_ENC_CHORD = 0, PF_ENC_TEXTURE = 1 };
+int pf_encoder_create(int kind, int input_dim, int emb_size, int hidden_dim, int z_dim, int num_channel, pf_encoder** out);
+void pf_encoder_destroy(pf_encoder* e);
+size_t pf_encoder_weight_bytes(const pf_encoder* e);
+int pf_encoder_pack_param(pf_encoder* e, const char* key, const float* src, const int64_t* shape, int ndim, void* host_blob);
+int pf_encoder_pack_missing(const pf_encoder* e, char* buf, size_t buf_len);
+int pf_encoder_bind_weights(pf_encoder* e, const void* dev_blob);
+size_t pf_encoder_workspace_bytes(const pf_encoder* e, int batch);
+/* chord:   x [B,T,input_dim] -> mu [B,z_dim];   texture: x [B,32,128] -> mu [B,z_dim] */
+int pf_encoder_forward(pf_encoder* e, const float* x, int batch, int n_step, float* mu,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-op entry points (unit-testable kernels; same kernels the plan launches) ---------- */
+/* Host helper: torch weight [N, K, kh, kw] (kh=kw=1 or 3) -> packed [kh*kw][K/4][Npad][4], Npad = roundup(N,64). */
+size_t pf_packed_gemm_weight_floats(int n, int k, int taps);
+int pf_pack_gemm_weight(const float* w, int n, int k, int taps, float* dst);
+
+/* GroupNorm statistics on NHWC (optionally the channel-concat of two tensors) -> per-(b,c)
+ * scale/shift so that y = x*scale + shift equals GroupNorm(x) (unet.py:321-336; eps 1e-5 / 1e-6). */
+int pf_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batch, int hw, int groups, float eps,
+                      const float* gamma, const float* beta, float* scale, float* shift,
+                      void* scratch, size_t scratch_bytes, void* stream);
+/* LayerNorm statistics over the last dim: mean[m], rstd[m] (unet_attention.py:104-110, eps 1e-5). */
+int pf_ln_stats(const float* x, int rows, int c, float eps, float* mean, float* rstd, void* stream);
+
+/* Implicit-GEMM convolution / linear on NHWC with fused prologue and epilogue (fp32 MFMA).
+ *   ks 1|3, stride 1|2, ups 0|1 (nearest x2 folded into the input read, unet.py:236-238)
+ *   prologue: 0 none | 1 y=silu(x*sc+sh) | 2 y=x*sc+sh (sc,sh [B][Cin]) | 3 LayerNorm (mean,rstd per row; sc,sh = gamma,beta [Cin])
+ *   epilogue: + bias[n] + sbias[b][n] + res[m][n]; geglu!=0: out[m][j] = v*gelu_erf(g) on interleaved halves */
+typedef struct pf_conv_args {
+  const float* x0; int32_t c0; const float* x1; int32_t c1; /* input = concat(x0, x1) along channels */
+  int32_t batch, hin, win;                                   /* input spatial size per sample (dense: hin=1, win=rows per sample) */
+  int32_t ks, stride, ups;
+  const float* w; int32_t n;                                 /* packed weights, logical N */
+  int32_t prologue; const float* sc; const float* sh; const float* mean; const float* rstd;
+  const float* bias; const float* sbias; int32_t ld_sbias; const float* res; int32_t ld_res;
+  int32_t geglu;
+  float* out; int32_t ld_out;
+} pf_conv_args;
+int pf_conv2d(const pf_conv_args* a, void* stream);
+
+/* softmax(q k^T * d_head^-0.5) v per (batch, head); q [B,Lq,*], k/v [B,Lk,*] with row strides ld*, heads packed
+ * along the last dim (unet_attention.py:261-293). d_head in {32,64}. */
+int pf_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                 int batch, int n_heads, int d_head, int lq, int lk, void* stream);
+
+/* Multi-GPU: one process per GPU.  The path shards over the batch with no exchange in the step
+ * loop; the single collective (weight broadcast at start-up) is issued by the host through
+ * torch.distributed (backend "nccl" = RCCL over xGMI) on the packed blob, so the library has
+ * no communicator of its own. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFHIP_H */

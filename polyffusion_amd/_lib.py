@@ -1,0 +1,133 @@
+"""ctypes binding of libpfhip.so (the C ABI in include/pfhip.h).
+
+There is no fallback: if the shared library is missing or a call fails, a RuntimeError
+is raised.  ``load()`` itself needs no GPU (the library dlopens on a CPU-only box, which
+the ``-m "not gpu"`` tests use to check the exported symbols); launching needs one.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpfhip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_i64_p = C.POINTER(C.c_int64)
+
+
+class UNetCfg(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("channels", C.c_int32), ("n_res_blocks", C.c_int32),
+        ("n_attention_levels", C.c_int32), ("attention_levels", C.c_int32 * 8),
+        ("n_levels", C.c_int32), ("channel_multipliers", C.c_int32 * 8),
+        ("n_heads", C.c_int32), ("tf_layers", C.c_int32), ("d_cond", C.c_int32),
+        ("img_h", C.c_int32), ("img_w", C.c_int32),
+    ]
+
+
+class DdpmCoef(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("c_recip", "c_recipm1", "c_x0", "c_xt", "sigma", "sqrt_ab", "sqrt_1mab")]
+
+
+class DdimCoef(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("s1m", "sqrt_a", "sqrt_aprev", "dir_coef", "sigma", "q_sqrt_a", "q_s1m")]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("x0", C.c_void_p), ("c0", C.c_int32), ("x1", C.c_void_p), ("c1", C.c_int32),
+        ("batch", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32),
+        ("ks", C.c_int32), ("stride", C.c_int32), ("ups", C.c_int32),
+        ("w", C.c_void_p), ("n", C.c_int32),
+        ("prologue", C.c_int32), ("sc", C.c_void_p), ("sh", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+        ("bias", C.c_void_p), ("sbias", C.c_void_p), ("ld_sbias", C.c_int32), ("res", C.c_void_p), ("ld_res", C.c_int32),
+        ("geglu", C.c_int32),
+        ("out", C.c_void_p), ("ld_out", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against include/pfhip.h
+SIGNATURES = {
+    "pf_version": (C.c_int, []),
+    "pf_last_error": (C.c_char_p, []),
+    "pf_unet_create": (C.c_int, [C.POINTER(UNetCfg), C.POINTER(C.c_void_p)]),
+    "pf_unet_destroy": (None, [C.c_void_p]),
+    "pf_unet_weight_bytes": (C.c_size_t, [C.c_void_p]),
+    "pf_unet_n_params": (C.c_int, [C.c_void_p]),
+    "pf_unet_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, c_i64_p, C.POINTER(C.c_int)]),
+    "pf_unet_pack_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_i64_p, C.c_int, C.c_void_p]),
+    "pf_unet_pack_missing": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "pf_unet_bind_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pf_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "pf_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_unet_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "pf_unet_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), c_float_p, C.POINTER(C.c_double), C.c_int]),
+    "pf_unet_n_launches": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "pf_cfg_combine": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_ddpm_step": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(DdpmCoef), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_axpby": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_ddim_step": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(DdimCoef), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_randn": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "pf_encoder_create": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_void_p)]),
+    "pf_encoder_destroy": (None, [C.c_void_p]),
+    "pf_encoder_weight_bytes": (C.c_size_t, [C.c_void_p]),
+    "pf_encoder_pack_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_i64_p, C.c_int, C.c_void_p]),
+    "pf_encoder_pack_missing": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "pf_encoder_bind_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pf_encoder_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "pf_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_packed_gemm_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "pf_pack_gemm_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pf_gn_scale_shift": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_ln_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "pf_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen libpfhip.so and attach prototypes.  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m polyffusion_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU fallback for this path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> int:
+    if rc < 0:
+        msg = load().pf_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libpfhip {what}: error {rc}: {msg}")
+    return rc
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("polyffusion_amd needs an AMD GPU (gfx950); no CPU fallback exists for the denoising path")
+
+
+def ptr(t) -> int:
+    """Raw device/host address of a torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,135 @@
+// norm_stats.hip - GroupNorm / LayerNorm statistics for gfx950.
+//
+// The normalisations themselves are never run as separate passes: the consumer GEMM/conv
+// applies y = x*scale + shift (GroupNorm) or (x-mean)*rstd*gamma+beta (LayerNorm) while it
+// stages its input tile (conv_mfma.hip).  These kernels only produce the statistics:
+//   GroupNorm32 / SpatialTransformer.norm (unet.py:321-336, unet_attention.py:40-42):
+//       per-(sample, channel) scale/shift from per-(sample, group) mean/var, on NHWC input
+//       that may be the channel-concat of two tensors (the U-Net skip concat is never
+//       materialised; a group may straddle the two sources, e.g. 256+128 channels).
+//   LayerNorm (unet_attention.py:104-110): per-row mean / rstd.
+// Both are HBM-bound single reads; per-thread partial sums are short fp32 runs, all
+// cross-thread / cross-block accumulation is done in fp64 and is deterministic (no atomics).
+#include "pf_internal.h"
+
+namespace pf {
+
+static inline int gn_nsplit(int hw) {
+  int n = hw / 256;
+  if (n < 1) n = 1;
+  if (n > 64) n = 64;
+  return n;
+}
+
+size_t gn_scratch_bytes(int batch, int c, int hw) { return (size_t)batch * gn_nsplit(hw) * c * 2 * sizeof(double); }
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x0, int c0, const float* __restrict__ x1,
+                                                         int c1, int hw, int nsplit, double* __restrict__ part) {
+  __shared__ double red[256 * 8];
+  const int C = c0 + c1, CQ = C / 4, PL = 256 / CQ;
+  const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int chunk = (hw + nsplit - 1) / nsplit;
+  const int p0 = s * chunk, p1 = min(hw, p0 + chunk);
+  const int pl = tid / CQ, cq = tid % CQ;
+  float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (pl < PL) {
+    const int ch = cq * 4;
+    const float* src; int cs, co;
+    if (ch < c0) { src = x0; cs = c0; co = ch; } else { src = x1; cs = c1; co = ch - c0; }
+    for (int pix = p0 + pl; pix < p1; pix += PL) {
+      const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)b * hw + pix) * cs + co);
+      sm[0] += v.x; sm[1] += v.y; sm[2] += v.z; sm[3] += v.w;
+      sq[0] += v.x * v.x; sq[1] += v.y * v.y; sq[2] += v.z * v.z; sq[3] += v.w * v.w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { red[tid * 8 + i] = sm[i]; red[tid * 8 + 4 + i] = sq[i]; }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    double a = 0.0, q = 0.0;
+    const int cqq = c >> 2, ci = c & 3;
+    for (int l = 0; l < PL; ++l) { a += red[(l * CQ + cqq) * 8 + ci]; q += red[(l * CQ + cqq) * 8 + 4 + ci]; }
+    double* dst = part + (((size_t)b * nsplit + s) * C + c) * 2;
+    dst[0] = a; dst[1] = q;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, int C, int hw, int nsplit, int groups,
+                                                          float eps, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tpg = 256 / groups;  // threads per group (power of two, <= 64)
+  const int g = tid / tpg, j = tid % tpg;
+  const int gs = C / groups;
+  double a = 0.0, q = 0.0;
+  for (int i = j; i < nsplit * gs; i += tpg) {
+    const int s = i / gs, c = g * gs + i % gs;
+    const double* src = part + (((size_t)b * nsplit + s) * C + c) * 2;
+    a += src[0]; q += src[1];
+  }
+  for (int off = tpg >> 1; off > 0; off >>= 1) { a += __shfl_xor(a, off); q += __shfl_xor(q, off); }
+  const double cnt = (double)gs * hw;
+  const double mean = a / cnt;
+  double var = q / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  for (int i = j; i < gs; i += tpg) {
+    const int c = g * gs + i;
+    const double ga = gamma[c];
+    scale[(size_t)b * C + c] = (float)(rstd * ga);
+    shift[(size_t)b * C + c] = (float)((double)beta[c] - mean * rstd * ga);
+  }
+}
+
+int launch_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batch, int hw, int groups, float eps,
+                          const float* gamma, const float* beta, float* scale, float* shift, void* scratch,
+                          size_t scratch_bytes, hipStream_t stream) {
+  const int C = c0 + c1;
+  PF_REQUIRE(x0 && c0 > 0 && c0 % 4 == 0 && c1 % 4 == 0 && (c1 == 0 || x1), "gn: bad inputs (c0=%d c1=%d)", c0, c1);
+  PF_REQUIRE(C <= 1024, "gn: at most 1024 channels (got %d)", C);
+  PF_REQUIRE(groups > 0 && 256 % groups == 0 && groups >= 4 && C % groups == 0, "gn: groups=%d unsupported for C=%d", groups, C);
+  PF_REQUIRE(scratch && scratch_bytes >= gn_scratch_bytes(batch, C, hw), "gn: scratch too small");
+  const int ns = gn_nsplit(hw);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(ns, batch), dim3(256), 0, stream, x0, c0, x1, c1, hw, ns, (double*)scratch);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, (const double*)scratch, C, hw, ns, groups, eps,
+                     gamma, beta, scale, shift);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+// One wave per row; two passes over the (L1/L2-resident) row: mean, then centred variance.
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, int rows, int C, float eps,
+                                                       float* __restrict__ mean, float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * C;
+  float s = 0.f;
+  for (int k = lane * 4; k < C; k += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + k);
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mu = s / (float)C;
+  float q = 0.f;
+  for (int k = lane * 4; k < C; k += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + k);
+    const float a = v.x - mu, b = v.y - mu, c = v.z - mu, d = v.w - mu;
+    q += (a * a + b * b) + (c * c + d * d);
+  }
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = 1.0f / sqrtf(q / (float)C + eps);
+  }
+}
+
+int launch_ln_stats(const float* x, int rows, int c, float eps, float* mean, float* rstd, hipStream_t stream) {
+  PF_REQUIRE(x && mean && rstd && rows > 0 && c > 0 && c % 4 == 0, "ln_stats: bad arguments");
+  hipLaunchKernelGGL(ln_stats_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, rows, c, eps, mean, rstd);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+}  // namespace pf

@@ -1,0 +1,70 @@
+// Internal declarations shared by the translation units of libpfhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include "../../include/pfhip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace pf {
+
+int set_error(int code, const char* fmt, ...);
+
+#define PF_CHECK_HIP(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) return pf::set_error(PF_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+#define PF_REQUIRE(cond, ...)                                   \
+  do {                                                          \
+    if (!(cond)) return pf::set_error(PF_EINVAL, __VA_ARGS__);  \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- launchers implemented in the .hip files (all enqueue on `stream`, never sync) ----
+int launch_conv(const pf_conv_args& a, hipStream_t stream);
+double conv_flops(const pf_conv_args& a);
+
+int launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                     int batch, int n_heads, int d_head, int lq, int lk, hipStream_t stream);
+
+size_t gn_scratch_bytes(int batch, int c, int hw);
+int launch_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batch, int hw, int groups, float eps,
+                          const float* gamma, const float* beta, float* scale, float* shift, void* scratch,
+                          size_t scratch_bytes, hipStream_t stream);
+int launch_ln_stats(const float* x, int rows, int c, float eps, float* mean, float* rstd, hipStream_t stream);
+
+// stem / head convolutions (NCHW <-> NHWC at the ABI edge)
+int launch_conv_in(const float* x_nchw, const float* w /*[Cout][Cin][3][3]*/, const float* bias, float* out_nhwc,
+                   int batch, int cin, int cout, int h, int w_, hipStream_t stream);
+int launch_conv_out(const float* x_nhwc, const float* sc, const float* sh, const float* w /*[Cout][9][Cin]*/,
+                    const float* bias, float* out_nchw, int batch, int cin, int cout, int h, int w_, hipStream_t stream);
+
+// time embedding: t[B] -> silu(time_embed(sinusoid(t))) [B][d_t]
+int launch_time_embed(const int64_t* t, const float* w0, const float* b0, const float* w2, const float* b2,
+                      float* out_silu, int batch, int channels, int d_t, hipStream_t stream);
+// y[b][n] = sum_k W[n][k] * x[b][k] + bias[n]   (row-major W [N][K]; one wave per output)
+int launch_matvec(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int batch, int n, int k,
+                  hipStream_t stream);
+
+// sampler elementwise kernels
+int launch_cfg_combine(const float* eps2, float scale, float* eps, size_t n, hipStream_t s);
+int launch_ddpm_step(const float* x, const float* eps, const float* noise_p, const float* noise_q, const float* orig,
+                     const float* mask, const pf_ddpm_coef& c, float* out, size_t n, hipStream_t s);
+int launch_axpby(const float* x, const float* y, float a, float b, float* out, size_t n, hipStream_t s);
+int launch_ddim_step(const float* x, const float* eps, const float* noise, const float* orig, const float* orig_noise,
+                     const float* mask, const pf_ddim_coef& c, float* out, size_t n, hipStream_t s);
+int launch_randn(float* out, size_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, hipStream_t s);
+
+// encoder kernels
+int launch_gru_gates(const float* gi, int ld_gi, const float* gh, float* h, int ld_h, int batch, int hidden, hipStream_t s);
+int launch_txt_frontend(const float* pr, const float* w, const float* bias, float* out, int batch, int num_channel,
+                        hipStream_t s);
+
+}  // namespace pf

@@ -1,0 +1,398 @@
+// small_kernels.hip - the memory-bound / tiny kernels of the path (gfx950):
+//   stem and head convolutions (NCHW <-> NHWC at the ABI edge, unet.py:78-80,145-149),
+//   timestep embedding MLP (unet.py:63-68,151-169), batched mat-vec (ResBlock emb_layers
+//   unet.py:286-289; n_cond==1 cross-attention collapse unet_attention.py:186-212),
+//   fused sampler updates (sampler_sdf.py:80-171,307-341; sampler_ddim.py:220-272,355-359),
+//   counter-based Gaussian noise, GRU gate update and the texture-encoder front end
+//   (dl_modules/chord_enc.py:15-22, txt_enc.py:23-27).
+#include "pf_internal.h"
+
+namespace pf {
+
+__device__ __forceinline__ float silu_s(float v) { return v / (1.0f + __expf(-v)); }
+
+// ------------------------------------------------------------------ stem conv (Cin tiny)
+// thread = (pixel, 4 output channels); x NCHW, out NHWC. Weights [Cout][Cin][3][3] read through LDS.
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int B, int Cin,
+                                                      int Cout, int H, int W) {
+  extern __shared__ float sw[];  // [Cout][Cin*9]
+  const int K = Cin * 9;
+  for (int i = threadIdx.x; i < Cout * K; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const int CQ = Cout / 4;
+  const size_t total = (size_t)B * H * W * CQ;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int cq = (int)(idx % CQ);
+    const size_t pix = idx / CQ;
+    const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
+    float acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = bias[cq * 4 + j];
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* xp = x + ((size_t)b * Cin + ci) * H * W;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int iy = yh + r - 1;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int ix = xw + s - 1;
+          if (ix < 0 || ix >= W) continue;
+          const float v = xp[(size_t)iy * W + ix];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(v, sw[(cq * 4 + j) * K + ci * 9 + r * 3 + s], acc[j]);
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(out + pix * Cout + cq * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+int launch_conv_in(const float* x, const float* w, const float* bias, float* out, int batch, int cin, int cout, int h, int w_,
+                   hipStream_t stream) {
+  PF_REQUIRE(cout % 4 == 0 && (size_t)cout * cin * 9 * 4 <= 64 * 1024, "conv_in: unsupported channel counts %d->%d", cin, cout);
+  const size_t total = (size_t)batch * h * w_ * (cout / 4);
+  const int grid = (int)min((size_t)4096, (total + 255) / 256);
+  hipLaunchKernelGGL(conv_in_kernel, dim3(grid), dim3(256), (size_t)cout * cin * 9 * sizeof(float), stream, x, w, bias, out, batch,
+                     cin, cout, h, w_);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+// ------------------------------------------------------------------ head: GN+SiLU -> conv3x3 -> few channels, NCHW out
+// 16x16 output pixels per block; the transformed 18x18 halo is staged in LDS 16 channels at a time.
+// Weights are pre-packed [Cout][9][Cin].
+template <int COUT_MAX>
+__global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__ x, const float* __restrict__ sc,
+                                                       const float* __restrict__ sh, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int B, int Cin,
+                                                       int Cout, int H, int W) {
+  constexpr int T = 16, TI = T + 2, CK = 16, CP = CK + 4;
+  __shared__ __attribute__((aligned(16))) float sx[TI * TI * CP];
+  extern __shared__ __attribute__((aligned(16))) float swt[];  // [Cout][9][Cin]
+  const int tid = threadIdx.x;
+  const int tilesx = (W + T - 1) / T, tilesy = (H + T - 1) / T;
+  int bid = blockIdx.x;
+  const int tx = bid % tilesx; bid /= tilesx;
+  const int ty = bid % tilesy;
+  const int b = bid / tilesy;
+  for (int i = tid; i < Cout * 9 * Cin; i += 256) swt[i] = w[i];
+  const int py = tid / T, px = tid % T;
+  float acc[COUT_MAX];
+#pragma unroll
+  for (int co = 0; co < COUT_MAX; ++co) acc[co] = 0.f;
+  for (int c0 = 0; c0 < Cin; c0 += CK) {
+    __syncthreads();
+    for (int u = tid; u < TI * TI * (CK / 4); u += 256) {
+      const int c4 = u % (CK / 4), pix = u / (CK / 4);
+      const int iy = ty * T + pix / TI - 1, ix = tx * T + pix % TI - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + iy) * W + ix) * Cin + c0 + c4 * 4);
+        const float4 a = *reinterpret_cast<const float4*>(sc + (size_t)b * Cin + c0 + c4 * 4);
+        const float4 d = *reinterpret_cast<const float4*>(sh + (size_t)b * Cin + c0 + c4 * 4);
+        v.x = silu_s(v.x * a.x + d.x); v.y = silu_s(v.y * a.y + d.y);
+        v.z = silu_s(v.z * a.z + d.z); v.w = silu_s(v.w * a.w + d.w);
+      }
+      *reinterpret_cast<float4*>(sx + pix * CP + c4 * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const float* xp = sx + ((py + r) * TI + px + s) * CP;
+#pragma unroll
+        for (int c4 = 0; c4 < CK / 4; ++c4) {
+          const float4 v = *reinterpret_cast<const float4*>(xp + c4 * 4);
+#pragma unroll
+          for (int co = 0; co < COUT_MAX; ++co) {
+            if (co < Cout) {
+              const float4 ww = *reinterpret_cast<const float4*>(swt + ((size_t)co * 9 + r * 3 + s) * Cin + c0 + c4 * 4);
+              acc[co] = fmaf(v.x, ww.x, acc[co]); acc[co] = fmaf(v.y, ww.y, acc[co]);
+              acc[co] = fmaf(v.z, ww.z, acc[co]); acc[co] = fmaf(v.w, ww.w, acc[co]);
+            }
+          }
+        }
+      }
+  }
+  const int oy = ty * T + py, ox = tx * T + px;
+  if (oy < H && ox < W) {
+#pragma unroll
+    for (int co = 0; co < COUT_MAX; ++co)
+      if (co < Cout) out[(((size_t)b * Cout + co) * H + oy) * W + ox] = acc[co] + bias[co];
+  }
+}
+
+int launch_conv_out(const float* x, const float* sc, const float* sh, const float* w, const float* bias, float* out, int batch,
+                    int cin, int cout, int h, int w_, hipStream_t stream) {
+  PF_REQUIRE(cout >= 1 && cout <= 4 && cin % 16 == 0, "conv_out: unsupported channel counts %d->%d", cin, cout);
+  const size_t lds = (size_t)cout * 9 * cin * sizeof(float);
+  PF_REQUIRE(lds <= 32 * 1024, "conv_out: weights do not fit LDS");
+  const int grid = batch * cdiv(h, 16) * cdiv(w_, 16);
+  hipLaunchKernelGGL(conv_out_kernel<4>, dim3(grid), dim3(256), lds, stream, x, sc, sh, w, bias, out, batch, cin, cout, h, w_);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+// ------------------------------------------------------------------ timestep embedding MLP
+// out[b][:] = silu( W2 . silu(W0 . [cos(t f) | sin(t f)] + b0) + b2 )   (the SiLU of emb_layers is folded in)
+__global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restrict__ t, const float* __restrict__ w0,
+                                                         const float* __restrict__ b0, const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, float* __restrict__ out, int channels,
+                                                         int d_t) {
+  extern __shared__ float sm[];  // e[channels] | h[d_t]
+  float* e = sm;
+  float* hbuf = sm + channels;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int half = channels / 2;
+  const float tv = (float)t[b];
+  for (int i = tid; i < 2 * half; i += 256) {
+    const int j = i % half;
+    float a = -9.210340371976184f * (float)j;  // -ln(10000) * j / half, evaluated in fp32 like the reference
+    a = a / (float)half;
+    const float arg = tv * expf(a);
+    e[i] = (i < half) ? cosf(arg) : sinf(arg);
+  }
+  __syncthreads();
+  for (int n = tid; n < d_t; n += 256) {
+    float acc = b0[n];
+    const float* wr = w0 + (size_t)n * channels;
+    for (int k = 0; k < channels; ++k) acc = fmaf(wr[k], e[k], acc);
+    hbuf[n] = silu_s(acc);
+  }
+  __syncthreads();
+  for (int n = tid; n < d_t; n += 256) {
+    float acc = b2[n];
+    const float* wr = w2 + (size_t)n * d_t;
+    for (int k = 0; k < d_t; ++k) acc = fmaf(wr[k], hbuf[k], acc);
+    out[(size_t)b * d_t + n] = silu_s(acc);
+  }
+}
+
+int launch_time_embed(const int64_t* t, const float* w0, const float* b0, const float* w2, const float* b2, float* out_silu,
+                      int batch, int channels, int d_t, hipStream_t stream) {
+  PF_REQUIRE(channels % 2 == 0 && channels + d_t <= 8192, "time_embed: unsupported sizes");
+  hipLaunchKernelGGL(time_embed_kernel, dim3(batch), dim3(256), (size_t)(channels + d_t) * sizeof(float), stream, t, w0, b0, w2,
+                     b2, out_silu, channels, d_t);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+// ------------------------------------------------------------------ batched mat-vec: y[b][n] = W[n][:] . x[b][:] + bias[n]
+// one wave per output n (8 outputs per wave), 8 batch rows per block so each weight row is read once per 8 samples.
+__global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ y, int ldy, int B, int N,
+                                                     int K) {
+  constexpr int RB = 8, OPW = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b0 = blockIdx.y * RB;
+  const int nb = min(RB, B - b0);
+  const bool vec = (K % 4 == 0) && (ldx % 4 == 0);
+  for (int o = 0; o < OPW; ++o) {
+    const int n = (blockIdx.x * 4 + wave) * OPW + o;
+    if (n >= N) return;
+    const float* wr = w + (size_t)n * K;
+    float acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+    if (vec) {
+      for (int k = lane * 4; k < K; k += 256) {
+        const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          if (r < nb) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)(b0 + r) * ldx + k);
+            acc[r] += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
+          }
+      }
+    } else {
+      for (int k = lane; k < K; k += 64) {
+        const float wv = wr[k];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          if (r < nb) acc[r] = fmaf(wv, x[(size_t)(b0 + r) * ldx + k], acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      float v = acc[r];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0 && r < nb) y[(size_t)(b0 + r) * ldy + n] = v + (bias ? bias[n] : 0.f);
+    }
+  }
+}
+
+int launch_matvec(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int batch, int n, int k,
+                  hipStream_t stream) {
+  PF_REQUIRE(x && w && y && batch > 0 && n > 0 && k > 0, "matvec: bad arguments");
+  hipLaunchKernelGGL(matvec_kernel, dim3(cdiv(n, 32), cdiv(batch, 8)), dim3(256), 0, stream, x, ldx, w, bias, y, ldy, batch, n, k);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+// ------------------------------------------------------------------ sampler elementwise kernels
+static inline dim3 ew_grid(size_t n) { return dim3((unsigned)min((size_t)2048, (n + 255) / 256)); }
+
+__global__ void cfg_combine_kernel(const float* __restrict__ e2, float s, float* __restrict__ e, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float u = e2[i], c = e2[n + i];
+    e[i] = u + s * (c - u);
+  }
+}
+int launch_cfg_combine(const float* eps2, float scale, float* eps, size_t n, hipStream_t s) {
+  PF_REQUIRE(eps2 && eps && n > 0, "cfg_combine: bad arguments");
+  hipLaunchKernelGGL(cfg_combine_kernel, ew_grid(n), dim3(256), 0, s, eps2, scale, eps, n);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+__global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ np,
+                                 const float* __restrict__ nq, const float* __restrict__ orig, const float* __restrict__ mask,
+                                 pf_ddpm_coef c, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float xv = x[i];
+    // same operation order as the reference (each product rounded, then the sum)
+    const float x0 = __fsub_rn(__fmul_rn(c.c_recip, xv), __fmul_rn(c.c_recipm1, eps[i]));
+    const float mean = __fadd_rn(__fmul_rn(c.c_x0, x0), __fmul_rn(c.c_xt, xv));
+    float xu = mean;
+    if (np) xu = __fadd_rn(mean, __fmul_rn(c.sigma, np[i]));
+    if (orig) {
+      float xk = __fmul_rn(c.sqrt_ab, orig[i]);
+      if (nq) xk = __fadd_rn(xk, __fmul_rn(c.sqrt_1mab, nq[i]));
+      const float m = mask[i];
+      xu = __fadd_rn(__fmul_rn(xk, m), __fmul_rn(xu, 1.0f - m));
+    }
+    out[i] = xu;
+  }
+}
+int launch_ddpm_step(const float* x, const float* eps, const float* noise_p, const float* noise_q, const float* orig,
+                     const float* mask, const pf_ddpm_coef& c, float* out, size_t n, hipStream_t s) {
+  PF_REQUIRE(x && eps && out && n > 0 && (!orig || mask), "ddpm_step: bad arguments");
+  hipLaunchKernelGGL(ddpm_step_kernel, ew_grid(n), dim3(256), 0, s, x, eps, noise_p, noise_q, orig, mask, c, out, n);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float a, float b, float* __restrict__ out,
+                             size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = __fadd_rn(__fmul_rn(a, x[i]), __fmul_rn(b, y[i]));
+}
+int launch_axpby(const float* x, const float* y, float a, float b, float* out, size_t n, hipStream_t s) {
+  PF_REQUIRE(x && y && out && n > 0, "axpby: bad arguments");
+  hipLaunchKernelGGL(axpby_kernel, ew_grid(n), dim3(256), 0, s, x, y, a, b, out, n);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
+                                 const float* __restrict__ orig, const float* __restrict__ on, const float* __restrict__ mask,
+                                 pf_ddim_coef c, float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float e = eps[i];
+    const float p0 = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(c.s1m, e)), c.sqrt_a);
+    float xp = __fadd_rn(__fmul_rn(c.sqrt_aprev, p0), __fmul_rn(c.dir_coef, e));
+    if (noise) xp = __fadd_rn(xp, __fmul_rn(c.sigma, noise[i]));
+    if (orig) {
+      const float ot = __fadd_rn(__fmul_rn(c.q_sqrt_a, orig[i]), __fmul_rn(c.q_s1m, on[i]));
+      const float m = mask[i];
+      xp = __fadd_rn(__fmul_rn(ot, m), __fmul_rn(xp, 1.0f - m));
+    }
+    out[i] = xp;
+  }
+}
+int launch_ddim_step(const float* x, const float* eps, const float* noise, const float* orig, const float* orig_noise,
+                     const float* mask, const pf_ddim_coef& c, float* out, size_t n, hipStream_t s) {
+  PF_REQUIRE(x && eps && out && n > 0 && (!orig || (mask && orig_noise)), "ddim_step: bad arguments");
+  hipLaunchKernelGGL(ddim_step_kernel, ew_grid(n), dim3(256), 0, s, x, eps, noise, orig, orig_noise, mask, c, out, n);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 + Box-Muller
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__global__ void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed, uint64_t sid, uint64_t off) {
+  const uint64_t g0 = off >> 2, g1 = (off + n + 3) >> 2;
+  for (uint64_t g = g0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t c0 = (uint32_t)g, c1 = (uint32_t)(g >> 32), c2 = (uint32_t)sid, c3 = (uint32_t)(sid >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    float sa, ca, sb, cb;
+    sincosf(6.283185307179586f * u1, &sa, &ca);
+    sincosf(6.283185307179586f * u3, &sb, &cb);
+    const float z[4] = {ra * ca, ra * sa, rb * cb, rb * sb};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t e = g * 4 + j;
+      if (e >= off && e < off + n) out[e - off] = z[j];
+    }
+  }
+}
+int launch_randn(float* out, size_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, hipStream_t s) {
+  PF_REQUIRE(out && n > 0, "randn: bad arguments");
+  hipLaunchKernelGGL(randn_kernel, ew_grid(n / 4 + 1), dim3(256), 0, s, out, n, seed, stream_id, elem_offset);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+// ------------------------------------------------------------------ GRU cell update (torch gate order r, z, n)
+// gi = W_ih x_t + b_ih  [B][3H] (row stride ld_gi), gh = W_hh h + b_hh [B][3H]
+__global__ void gru_gates_kernel(const float* __restrict__ gi, int ld_gi, const float* __restrict__ gh, float* __restrict__ h,
+                                 int ld_h, int B, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * H) return;
+  const int b = i / H, j = i % H;
+  const float* a = gi + (size_t)b * ld_gi;
+  const float* c = gh + (size_t)b * 3 * H;
+  const float r = 1.0f / (1.0f + expf(-(a[j] + c[j])));
+  const float z = 1.0f / (1.0f + expf(-(a[H + j] + c[H + j])));
+  const float nn = tanhf(a[2 * H + j] + r * c[2 * H + j]);
+  float* hp = h + (size_t)b * ld_h + j;
+  *hp = (1.0f - z) * nn + z * *hp;
+}
+int launch_gru_gates(const float* gi, int ld_gi, const float* gh, float* h, int ld_h, int batch, int hidden, hipStream_t s) {
+  hipLaunchKernelGGL(gru_gates_kernel, dim3(cdiv(batch * hidden, 256)), dim3(256), 0, s, gi, ld_gi, gh, h, ld_h, batch, hidden);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+// ------------------------------------------------------------------ texture encoder front end
+// pr [B,32,128] -> conv(1->C,(4,12),stride(4,1)) -> ReLU -> maxpool(1,4) -> [B,C,8,29] (contiguous; the
+// reference then reinterprets this buffer as [B,8,C*29] without a permute - txt_enc.py:27).
+__global__ void txt_frontend_kernel(const float* __restrict__ pr, const float* __restrict__ w, const float* __restrict__ bias,
+                                    float* __restrict__ out, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = B * C * 8 * 29;
+  if (i >= total) return;
+  const int pw = i % 29, row = (i / 29) % 8, ch = (i / (29 * 8)) % C, b = i / (29 * 8 * C);
+  const float* src = pr + (size_t)b * 32 * 128 + (size_t)row * 4 * 128;
+  const float* wk = w + (size_t)ch * 48;
+  float best = 0.f;  // ReLU floor
+  for (int q = 0; q < 4; ++q) {
+    const int col = pw * 4 + q;
+    float acc = bias[ch];
+    for (int r = 0; r < 4; ++r)
+      for (int s = 0; s < 12; ++s) acc = fmaf(src[r * 128 + col + s], wk[r * 12 + s], acc);
+    best = fmaxf(best, acc);
+  }
+  out[i] = best;
+}
+int launch_txt_frontend(const float* pr, const float* w, const float* bias, float* out, int batch, int num_channel, hipStream_t s) {
+  hipLaunchKernelGGL(txt_frontend_kernel, dim3(cdiv(batch * num_channel * 8 * 29, 256)), dim3(256), 0, s, pr, w, bias, out, batch,
+                     num_channel);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+}  // namespace pf

@@ -1,0 +1,766 @@
+// unet.hip - host-side plan of the denoiser forward and the pf_unet_* C ABI.
+//
+// The architecture walk follows the reference constructor (unet.py:30-149) and forward
+// (unet.py:171-196); every arithmetic step is a launch of one of the gfx950 kernels in
+// conv_mfma.hip / attention.hip / norm_stats.hip / small_kernels.hip.  No device memory is
+// allocated here: weights live in ONE caller-owned packed blob, activations in a
+// caller-owned workspace carved by two bump allocators (persistent block outputs = the
+// U-Net skips; per-layer temporaries that are recycled layer after layer).
+#include <stdarg.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <vector>
+#include "pf_internal.h"
+
+namespace pf {
+
+static thread_local std::string g_err;
+int set_error(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+enum DestKind { D_RAW = 0, D_GEMM = 1, D_GEGLU_W = 2, D_GEGLU_B = 3, D_CONVOUT = 4 };
+struct Dest { int kind; size_t off; int taps, K, N, Npad, n_off; };
+struct ParamSpec { std::string key; std::vector<int64_t> shape; std::vector<Dest> dests; bool packed = false; };
+
+struct Layer {
+  int kind;  // 0 conv_in, 1 res, 2 st, 3 down, 4 up
+  int cin, cout;
+  // offsets (floats) into the packed blob
+  size_t gn1_g, gn1_b, w1, b1, gn2_g, gn2_b, w2, b2, wskip, bskip;  // res; conv: w1/b1
+  int emb_off;                                                        // column offset into the all-ResBlock time-bias matrix
+  // spatial transformer
+  size_t norm_g, norm_b, pin_w, pin_b, pout_w, pout_b;
+  struct TB { size_t n1g, n1b, n2g, n2b, n3g, n3b, qkv, o1w, o1b, q2, kv2, o2w, o2b, v2raw, o2raw, ff1w, ff1b, ff2w, ff2b; };
+  std::vector<TB> tbs;
+  int st_index;
+};
+struct Block { std::vector<Layer> layers; };
+
+}  // namespace pf
+
+using namespace pf;
+
+struct pf_unet {
+  pf_unet_cfg cfg;
+  std::vector<Block> in_blocks, out_blocks;
+  Block mid;
+  std::vector<int> skip_ch;
+  int final_ch = 0, n_st = 0, sum_emb = 0, d_t = 0;
+  std::vector<ParamSpec> params;
+  std::map<std::string, int> index;
+  size_t blob_floats = 0;
+  size_t te_w0, te_b0, te_w2, te_b2, emb_w, emb_b, out_g, out_b, out_w, out_bias, in_w, in_b;
+  const float* wdev = nullptr;
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> pkind;
+  std::vector<double> pflops;
+  int n_prof = 0;
+
+  size_t alloc(size_t nfloats) { size_t o = blob_floats; blob_floats += (nfloats + 63) / 64 * 64; return o; }
+  ParamSpec& add(const std::string& key, std::vector<int64_t> shape) {
+    index[key] = (int)params.size();
+    params.push_back(ParamSpec{key, shape, {}, false});
+    return params.back();
+  }
+  size_t add_raw(const std::string& key, std::vector<int64_t> shape) {
+    size_t n = 1; for (auto s : shape) n *= (size_t)s;
+    size_t off = alloc(n);
+    add(key, shape).dests.push_back(Dest{D_RAW, off, 1, 0, 0, 0, 0});
+    return off;
+  }
+  // raw copy into a pre-allocated region at a float offset
+  void add_raw_at(const std::string& key, std::vector<int64_t> shape, size_t off) {
+    add(key, shape).dests.push_back(Dest{D_RAW, off, 1, 0, 0, 0, 0});
+  }
+  static size_t gemm_floats(int taps, int K, int N) { return (size_t)taps * K * ((N + 63) / 64 * 64); }
+  size_t add_gemm(const std::string& key, int N, int K, int taps) {
+    size_t off = alloc(gemm_floats(taps, K, N));
+    std::vector<int64_t> shape = taps == 1 ? std::vector<int64_t>{N, K} : std::vector<int64_t>{N, K, 3, 3};
+    add(key, shape).dests.push_back(Dest{D_GEMM, off, taps, K, N, (N + 63) / 64 * 64, 0});
+    return off;
+  }
+};
+
+namespace pf {
+
+static void build_res(pf_unet* u, const std::string& p, Layer& L) {
+  const int ci = L.cin, co = L.cout;
+  L.gn1_g = u->add_raw(p + ".in_layers.0.weight", {ci});
+  L.gn1_b = u->add_raw(p + ".in_layers.0.bias", {ci});
+  L.w1 = u->add_gemm(p + ".in_layers.2.weight", co, ci, 9);
+  L.b1 = u->add_raw(p + ".in_layers.2.bias", {co});
+  L.emb_off = u->sum_emb;
+  u->sum_emb += co;
+  L.gn2_g = u->add_raw(p + ".out_layers.0.weight", {co});
+  L.gn2_b = u->add_raw(p + ".out_layers.0.bias", {co});
+  L.w2 = u->add_gemm(p + ".out_layers.3.weight", co, co, 9);
+  L.b2 = u->add_raw(p + ".out_layers.3.bias", {co});
+  if (ci != co) {
+    L.wskip = u->add_gemm(p + ".skip_connection.weight", co, ci, 1);
+    u->params.back().shape = {co, ci, 1, 1};
+    L.bskip = u->add_raw(p + ".skip_connection.bias", {co});
+  }
+}
+
+static void build_st(pf_unet* u, const std::string& p, Layer& L) {
+  const int C = L.cin, dc = u->cfg.d_cond;
+  L.st_index = u->n_st++;
+  L.norm_g = u->add_raw(p + ".norm.weight", {C});
+  L.norm_b = u->add_raw(p + ".norm.bias", {C});
+  L.pin_w = u->add_gemm(p + ".proj_in.weight", C, C, 1);
+  u->params.back().shape = {C, C, 1, 1};
+  L.pin_b = u->add_raw(p + ".proj_in.bias", {C});
+  for (int i = 0; i < u->cfg.tf_layers; ++i) {
+    Layer::TB t{};
+    const std::string tb = p + ".transformer_blocks." + std::to_string(i);
+    // attn1: q,k,v fused into one [C -> 3C] matrix
+    t.qkv = u->alloc(pf_unet::gemm_floats(1, C, 3 * C));
+    const char* nm[3] = {".attn1.to_q.weight", ".attn1.to_k.weight", ".attn1.to_v.weight"};
+    for (int j = 0; j < 3; ++j)
+      u->add(tb + nm[j], {C, C}).dests.push_back(Dest{D_GEMM, t.qkv, 1, C, C, (3 * C + 63) / 64 * 64, j * C});
+    t.o1w = u->add_gemm(tb + ".attn1.to_out.0.weight", C, C, 1);
+    t.o1b = u->add_raw(tb + ".attn1.to_out.0.bias", {C});
+    // attn2: general (n_cond > 1) form + collapsed (n_cond == 1) raw form of to_v / to_out
+    t.q2 = u->add_gemm(tb + ".attn2.to_q.weight", C, C, 1);
+    t.kv2 = u->alloc(pf_unet::gemm_floats(1, dc, 2 * C));
+    u->add(tb + ".attn2.to_k.weight", {C, dc}).dests.push_back(Dest{D_GEMM, t.kv2, 1, dc, C, (2 * C + 63) / 64 * 64, 0});
+    {
+      ParamSpec& ps = u->add(tb + ".attn2.to_v.weight", {C, dc});
+      ps.dests.push_back(Dest{D_GEMM, t.kv2, 1, dc, C, (2 * C + 63) / 64 * 64, C});
+      t.v2raw = u->alloc((size_t)C * dc);
+      u->params[u->index[tb + ".attn2.to_v.weight"]].dests.push_back(Dest{D_RAW, t.v2raw, 1, 0, 0, 0, 0});
+    }
+    t.o2w = u->add_gemm(tb + ".attn2.to_out.0.weight", C, C, 1);
+    t.o2raw = u->alloc((size_t)C * C);
+    u->params.back().dests.push_back(Dest{D_RAW, t.o2raw, 1, 0, 0, 0, 0});
+    t.o2b = u->add_raw(tb + ".attn2.to_out.0.bias", {C});
+    t.n1g = u->add_raw(tb + ".norm1.weight", {C}); t.n1b = u->add_raw(tb + ".norm1.bias", {C});
+    t.n2g = u->add_raw(tb + ".norm2.weight", {C}); t.n2b = u->add_raw(tb + ".norm2.bias", {C});
+    t.n3g = u->add_raw(tb + ".norm3.weight", {C}); t.n3b = u->add_raw(tb + ".norm3.bias", {C});
+    t.ff1w = u->alloc(pf_unet::gemm_floats(1, C, 8 * C));
+    u->add(tb + ".ff.net.0.proj.weight", {8 * C, C}).dests.push_back(Dest{D_GEGLU_W, t.ff1w, 1, C, 8 * C, 8 * C, 0});
+    t.ff1b = u->alloc((size_t)8 * C);
+    u->add(tb + ".ff.net.0.proj.bias", {8 * C}).dests.push_back(Dest{D_GEGLU_B, t.ff1b, 1, 0, 8 * C, 8 * C, 0});
+    t.ff2w = u->add_gemm(tb + ".ff.net.2.weight", C, 4 * C, 1);
+    t.ff2b = u->add_raw(tb + ".ff.net.2.bias", {C});
+    L.tbs.push_back(t);
+  }
+  L.pout_w = u->add_gemm(p + ".proj_out.weight", C, C, 1);
+  u->params.back().shape = {C, C, 1, 1};
+  L.pout_b = u->add_raw(p + ".proj_out.bias", {C});
+}
+
+static void build_layer(pf_unet* u, const std::string& p, Layer& L) {
+  switch (L.kind) {
+    case 0:
+      u->in_w = u->add_raw(p + ".weight", {L.cout, L.cin, 3, 3});
+      u->in_b = u->add_raw(p + ".bias", {L.cout});
+      break;
+    case 1: build_res(u, p, L); break;
+    case 2: build_st(u, p, L); break;
+    case 3:
+      L.w1 = u->add_gemm(p + ".op.weight", L.cout, L.cin, 9);
+      L.b1 = u->add_raw(p + ".op.bias", {L.cout});
+      break;
+    case 4:
+      L.w1 = u->add_gemm(p + ".conv.weight", L.cout, L.cin, 9);
+      L.b1 = u->add_raw(p + ".conv.bias", {L.cout});
+      break;
+  }
+}
+
+static bool in_list(const int32_t* v, int n, int x) {
+  for (int i = 0; i < n; ++i) if (v[i] == x) return true;
+  return false;
+}
+
+static int build(pf_unet* u) {
+  const pf_unet_cfg& c = u->cfg;
+  PF_REQUIRE(c.n_levels >= 1 && c.n_levels <= 8 && c.n_attention_levels >= 0 && c.n_attention_levels <= 8, "unet: bad level counts");
+  PF_REQUIRE(c.channels > 0 && c.channels % 32 == 0, "unet: channels must be a multiple of 32 (GroupNorm32), got %d", c.channels);
+  PF_REQUIRE(c.in_channels >= 1 && c.out_channels >= 1 && c.out_channels <= 4, "unet: out_channels must be 1..4");
+  PF_REQUIRE(c.n_heads > 0 && c.tf_layers >= 1 && c.d_cond > 0 && c.d_cond % 4 == 0, "unet: bad attention config");
+  PF_REQUIRE(c.img_h % (1 << (c.n_levels - 1)) == 0 && c.img_w % (1 << (c.n_levels - 1)) == 0, "unet: image size must be divisible by 2^(levels-1)");
+  u->d_t = c.channels * 4;
+  u->te_w0 = u->add_raw("time_embed.0.weight", {u->d_t, c.channels});
+  u->te_b0 = u->add_raw("time_embed.0.bias", {u->d_t});
+  u->te_w2 = u->add_raw("time_embed.2.weight", {u->d_t, u->d_t});
+  u->te_b2 = u->add_raw("time_embed.2.bias", {u->d_t});
+
+  int ch = c.channels;
+  std::vector<int> stack;
+  std::vector<int> widths;
+  for (int i = 0; i < c.n_levels; ++i) widths.push_back(c.channels * c.channel_multipliers[i]);
+  {
+    Block b; Layer L{}; L.kind = 0; L.cin = c.in_channels; L.cout = ch; b.layers.push_back(L);
+    u->in_blocks.push_back(b); stack.push_back(ch);
+  }
+  for (int lvl = 0; lvl < c.n_levels; ++lvl) {
+    const bool att = in_list(c.attention_levels, c.n_attention_levels, lvl);
+    for (int r = 0; r < c.n_res_blocks; ++r) {
+      Block b; Layer L{}; L.kind = 1; L.cin = ch; L.cout = widths[lvl]; b.layers.push_back(L);
+      ch = widths[lvl];
+      if (att) {
+        PF_REQUIRE(ch % c.n_heads == 0 && (ch / c.n_heads == 32 || ch / c.n_heads == 64), "unet: d_head %d unsupported (32 or 64)", ch / c.n_heads);
+        Layer S{}; S.kind = 2; S.cin = S.cout = ch; b.layers.push_back(S);
+      }
+      u->in_blocks.push_back(b); stack.push_back(ch);
+    }
+    if (lvl != c.n_levels - 1) {
+      Block b; Layer L{}; L.kind = 3; L.cin = L.cout = ch; b.layers.push_back(L);
+      u->in_blocks.push_back(b); stack.push_back(ch);
+    }
+  }
+  {
+    PF_REQUIRE(ch % c.n_heads == 0 && (ch / c.n_heads == 32 || ch / c.n_heads == 64), "unet: d_head %d unsupported (32 or 64)", ch / c.n_heads);
+    Layer a{}; a.kind = 1; a.cin = a.cout = ch;
+    Layer s{}; s.kind = 2; s.cin = s.cout = ch;
+    Layer d{}; d.kind = 1; d.cin = d.cout = ch;
+    u->mid.layers = {a, s, d};
+  }
+  for (int lvl = c.n_levels - 1; lvl >= 0; --lvl) {
+    const bool att = in_list(c.attention_levels, c.n_attention_levels, lvl);
+    for (int j = 0; j <= c.n_res_blocks; ++j) {
+      const int sk = stack.back(); stack.pop_back();
+      u->skip_ch.push_back(sk);
+      Block b; Layer L{}; L.kind = 1; L.cin = ch + sk; L.cout = widths[lvl]; b.layers.push_back(L);
+      ch = widths[lvl];
+      if (att) { Layer S{}; S.kind = 2; S.cin = S.cout = ch; b.layers.push_back(S); }
+      if (lvl != 0 && j == c.n_res_blocks) { Layer U{}; U.kind = 4; U.cin = U.cout = ch; b.layers.push_back(U); }
+      u->out_blocks.push_back(b);
+    }
+  }
+  u->final_ch = ch;
+
+  // parameter table in the reference key order
+  for (size_t bi = 0; bi < u->in_blocks.size(); ++bi)
+    for (size_t li = 0; li < u->in_blocks[bi].layers.size(); ++li)
+      build_layer(u, "input_blocks." + std::to_string(bi) + "." + std::to_string(li), u->in_blocks[bi].layers[li]);
+  for (size_t li = 0; li < u->mid.layers.size(); ++li) build_layer(u, "middle_block." + std::to_string(li), u->mid.layers[li]);
+  for (size_t bi = 0; bi < u->out_blocks.size(); ++bi)
+    for (size_t li = 0; li < u->out_blocks[bi].layers.size(); ++li)
+      build_layer(u, "output_blocks." + std::to_string(bi) + "." + std::to_string(li), u->out_blocks[bi].layers[li]);
+  u->out_g = u->add_raw("out.0.weight", {ch});
+  u->out_b = u->add_raw("out.0.bias", {ch});
+  u->out_w = u->alloc((size_t)c.out_channels * 9 * ch);
+  u->add("out.2.weight", {c.out_channels, ch, 3, 3}).dests.push_back(Dest{D_CONVOUT, u->out_w, 9, ch, c.out_channels, 0, 0});
+  u->out_bias = u->add_raw("out.2.bias", {c.out_channels});
+
+  // all ResBlock emb_layers concatenated into one [sum_emb][d_t] matrix (+ bias) for a single mat-vec launch
+  u->emb_w = u->alloc((size_t)u->sum_emb * u->d_t);
+  u->emb_b = u->alloc((size_t)u->sum_emb);
+  auto add_emb = [&](const std::string& p, Layer& L) {
+    if (L.kind != 1) return;
+    u->add_raw_at(p + ".emb_layers.1.weight", {L.cout, u->d_t}, u->emb_w + (size_t)L.emb_off * u->d_t);
+    u->add_raw_at(p + ".emb_layers.1.bias", {L.cout}, u->emb_b + L.emb_off);
+  };
+  for (size_t bi = 0; bi < u->in_blocks.size(); ++bi)
+    for (size_t li = 0; li < u->in_blocks[bi].layers.size(); ++li)
+      add_emb("input_blocks." + std::to_string(bi) + "." + std::to_string(li), u->in_blocks[bi].layers[li]);
+  for (size_t li = 0; li < u->mid.layers.size(); ++li) add_emb("middle_block." + std::to_string(li), u->mid.layers[li]);
+  for (size_t bi = 0; bi < u->out_blocks.size(); ++bi)
+    for (size_t li = 0; li < u->out_blocks[bi].layers.size(); ++li)
+      add_emb("output_blocks." + std::to_string(bi) + "." + std::to_string(li), u->out_blocks[bi].layers[li]);
+  return PF_OK;
+}
+
+// ---- weight repacking (host) ----
+static void pack_gemm(float* dst, const float* src, int n_src, int K, int taps, int Npad, int n_off) {
+  for (int n = 0; n < n_src; ++n)
+    for (int k = 0; k < K; ++k)
+      for (int t = 0; t < taps; ++t)
+        dst[(((size_t)t * (K / 4) + k / 4) * Npad + n_off + n) * 4 + (k & 3)] = src[((size_t)n * K + k) * taps + t];
+}
+static inline int geglu_col(int n, int inner) {  // torch row n of ff.net.0.proj -> packed column
+  const int j = n < inner ? n : n - inner;
+  return 64 * (j / 32) + (n < inner ? 0 : 32) + (j % 32);
+}
+
+static int pack_one(const ParamSpec& ps, const float* src, float* blob) {
+  size_t numel = 1; for (auto s : ps.shape) numel *= (size_t)s;
+  for (const Dest& d : ps.dests) {
+    float* dst = blob + d.off;
+    switch (d.kind) {
+      case D_RAW: memcpy(dst, src, numel * sizeof(float)); break;
+      case D_GEMM: pack_gemm(dst, src, d.N, d.K, d.taps, d.Npad, d.n_off); break;
+      case D_GEGLU_W: {
+        const int inner = d.N / 2;
+        for (int n = 0; n < d.N; ++n)
+          for (int k = 0; k < d.K; ++k) dst[((size_t)(k / 4) * d.Npad + geglu_col(n, inner)) * 4 + (k & 3)] = src[(size_t)n * d.K + k];
+        break;
+      }
+      case D_GEGLU_B: {
+        const int inner = d.N / 2;
+        for (int n = 0; n < d.N; ++n) dst[geglu_col(n, inner)] = src[n];
+        break;
+      }
+      case D_CONVOUT:  // [Cout][Cin][3][3] -> [Cout][9][Cin]
+        for (int co = 0; co < d.N; ++co)
+          for (int ci = 0; ci < d.K; ++ci)
+            for (int t = 0; t < 9; ++t) dst[((size_t)co * 9 + t) * d.K + ci] = src[((size_t)co * d.K + ci) * 9 + t];
+        break;
+    }
+  }
+  return PF_OK;
+}
+
+// ---- forward ----
+struct Ctx {
+  pf_unet* u; hipStream_t s; bool dry;
+  char* base; size_t persist_off, temp_base, temp_off, persist_max, temp_max;
+  int B, n_cond;
+  const float* W;
+  int n_launch;
+  int rc;
+  int cross_cmax;
+
+  float* palloc(size_t nfloats) {
+    size_t o = persist_off; persist_off += align_up(nfloats * 4, 256);
+    if (persist_off > persist_max) persist_max = persist_off;
+    return dry ? nullptr : (float*)(base + o);
+  }
+  float* talloc(size_t nfloats) {
+    size_t o = temp_off; temp_off += align_up(nfloats * 4, 256);
+    if (temp_off > temp_max) temp_max = temp_off;
+    return dry ? nullptr : (float*)(base + temp_base + o);
+  }
+  void treset() { temp_off = 0; }
+  const float* w(size_t off) const { return dry ? nullptr : W + off; }
+
+  void prof_begin(int kind, double flops) {
+    ++n_launch;
+    if (dry || !u->profiling) return;
+    const size_t need = (size_t)(u->n_prof + 1) * 2;
+    while (u->ev.size() < need) { hipEvent_t e; (void)hipEventCreate(&e); u->ev.push_back(e); }
+    u->pkind.push_back(kind); u->pflops.push_back(flops);
+    (void)hipEventRecord(u->ev[(size_t)u->n_prof * 2], s);
+  }
+  void prof_end() {
+    if (dry || !u->profiling) return;
+    (void)hipEventRecord(u->ev[(size_t)u->n_prof * 2 + 1], s);
+    ++u->n_prof;
+  }
+  void conv(const pf_conv_args& a, int kind) {
+    prof_begin(kind, conv_flops(a));
+    if (!dry && rc == PF_OK) rc = launch_conv(a, s);
+    prof_end();
+  }
+  void gn(const float* x0, int c0, const float* x1, int c1, int hw, float eps, size_t g, size_t b_, float* sc, float* sh) {
+    float* scratch = talloc(gn_scratch_bytes(B, c0 + c1, hw) / 4);
+    prof_begin(PF_K_GNSTAT, 0.0);
+    if (!dry && rc == PF_OK)
+      rc = launch_gn_scale_shift(x0, c0, x1, c1, B, hw, 32, eps, w(g), w(b_), sc, sh, scratch, gn_scratch_bytes(B, c0 + c1, hw), s);
+    prof_end();
+    ++n_launch;  // two kernels
+  }
+  void ln(const float* x, int rows, int c, float* mu, float* rs) {
+    prof_begin(PF_K_LNSTAT, 0.0);
+    if (!dry && rc == PF_OK) rc = launch_ln_stats(x, rows, c, 1e-5f, mu, rs, s);
+    prof_end();
+  }
+};
+
+static pf_conv_args conv_base(const float* x0, int c0, const float* x1, int c1, int B, int hin, int win, int ks,
+                              const float* wgt, int n, float* out) {
+  pf_conv_args a;
+  memset(&a, 0, sizeof a);
+  a.x0 = x0; a.c0 = c0; a.x1 = x1; a.c1 = c1; a.batch = B; a.hin = hin; a.win = win; a.ks = ks; a.stride = 1;
+  a.w = wgt; a.n = n; a.out = out; a.ld_out = n;
+  return a;
+}
+
+static float* run_res(Ctx& c, const Layer& L, const float* x0, int c0, const float* x1, int c1, int H, int W_, const float* tb_all) {
+  const int B = c.B, hw = H * W_, ci = L.cin, co = L.cout;
+  float* out = c.palloc((size_t)B * hw * co);
+  c.treset();
+  float* sc1 = c.talloc((size_t)B * ci); float* sh1 = c.talloc((size_t)B * ci);
+  float* h = c.talloc((size_t)B * hw * co);
+  float* sc2 = c.talloc((size_t)B * co); float* sh2 = c.talloc((size_t)B * co);
+  c.gn(x0, c0, x1, c1, hw, 1e-5f, L.gn1_g, L.gn1_b, sc1, sh1);
+  {
+    pf_conv_args a = conv_base(x0, c0, x1, c1, B, H, W_, 3, c.w(L.w1), co, h);
+    a.prologue = 1; a.sc = sc1; a.sh = sh1; a.bias = c.w(L.b1);
+    a.sbias = c.dry ? nullptr : tb_all + L.emb_off; a.ld_sbias = c.u->sum_emb;
+    c.conv(a, PF_K_CONV3);
+  }
+  c.gn(h, co, nullptr, 0, hw, 1e-5f, L.gn2_g, L.gn2_b, sc2, sh2);
+  const float* res = x0;
+  if (ci != co) {
+    float* sk = c.talloc((size_t)B * hw * co);
+    pf_conv_args a = conv_base(x0, c0, x1, c1, B, 1, hw, 1, c.w(L.wskip), co, sk);
+    a.bias = c.w(L.bskip);
+    c.conv(a, PF_K_GEMM);
+    res = sk;
+  }
+  {
+    pf_conv_args a = conv_base(h, co, nullptr, 0, B, H, W_, 3, c.w(L.w2), co, out);
+    a.prologue = 1; a.sc = sc2; a.sh = sh2; a.bias = c.w(L.b2); a.res = res; a.ld_res = co;
+    c.conv(a, PF_K_CONV3);
+  }
+  return out;
+}
+
+static float* run_st(Ctx& c, const Layer& L, const float* x, int H, int W_, const float* cond, const float* cross_all) {
+  const int B = c.B, hw = H * W_, C = L.cin, M = B * hw, nh = c.u->cfg.n_heads, dh = C / nh, dc = c.u->cfg.d_cond;
+  float* out = c.palloc((size_t)M * C);
+  c.treset();
+  float* sc = c.talloc((size_t)B * C); float* sh = c.talloc((size_t)B * C);
+  float* ta = c.talloc((size_t)M * C); float* tbuf = c.talloc((size_t)M * C); float* tc = c.talloc((size_t)M * C);
+  float* mu = c.talloc(M); float* rs = c.talloc(M);
+  float* qkv = c.talloc((size_t)M * 3 * C);
+  float* att = c.talloc((size_t)M * C);
+  float* ff = c.talloc((size_t)M * 4 * C);
+  float* kv = nullptr;
+  if (c.n_cond > 1) kv = c.talloc((size_t)B * c.n_cond * 2 * C);
+  c.gn(x, C, nullptr, 0, hw, 1e-6f, L.norm_g, L.norm_b, sc, sh);
+  {
+    pf_conv_args a = conv_base(x, C, nullptr, 0, B, 1, hw, 1, c.w(L.pin_w), C, ta);
+    a.prologue = 2; a.sc = sc; a.sh = sh; a.bias = c.w(L.pin_b);
+    c.conv(a, PF_K_GEMM);
+  }
+  float* t0 = ta; float* t1 = tbuf; float* t2 = tc;
+  for (size_t i = 0; i < L.tbs.size(); ++i) {
+    const Layer::TB& t = L.tbs[i];
+    // x = attn1(LN1(x)) + x
+    c.ln(t0, M, C, mu, rs);
+    {
+      pf_conv_args a = conv_base(t0, C, nullptr, 0, B, 1, hw, 1, c.w(t.qkv), 3 * C, qkv);
+      a.prologue = 3; a.sc = c.w(t.n1g); a.sh = c.w(t.n1b); a.mean = mu; a.rstd = rs;
+      c.conv(a, PF_K_GEMM);
+    }
+    c.prof_begin(PF_K_ATTN, 4.0 * B * nh * (double)hw * hw * dh);
+    if (!c.dry && c.rc == PF_OK) c.rc = launch_attention(qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, att, C, B, nh, dh, hw, hw, c.s);
+    c.prof_end();
+    {
+      pf_conv_args a = conv_base(att, C, nullptr, 0, B, 1, hw, 1, c.w(t.o1w), C, t1);
+      a.bias = c.w(t.o1b); a.res = t0; a.ld_res = C;
+      if (c.n_cond == 1) {  // x = attn2(LN2(x), c) + x collapses to a per-sample bias (softmax over one key == 1)
+        a.sbias = c.dry ? nullptr : cross_all + ((size_t)(L.st_index * c.u->cfg.tf_layers + i) * B) * c.cross_cmax;
+        a.ld_sbias = C;
+      }
+      c.conv(a, PF_K_GEMM);
+    }
+    if (c.n_cond > 1) {
+      c.ln(t1, M, C, mu, rs);
+      float* q2 = qkv;  // reuse: [M][C]
+      {
+        pf_conv_args a = conv_base(t1, C, nullptr, 0, B, 1, hw, 1, c.w(t.q2), C, q2);
+        a.prologue = 3; a.sc = c.w(t.n2g); a.sh = c.w(t.n2b); a.mean = mu; a.rstd = rs;
+        c.conv(a, PF_K_GEMM);
+      }
+      {
+        pf_conv_args a = conv_base(cond, dc, nullptr, 0, B, 1, c.n_cond, 1, c.w(t.kv2), 2 * C, kv);
+        c.conv(a, PF_K_GEMM);
+      }
+      c.prof_begin(PF_K_ATTN, 4.0 * B * nh * (double)hw * c.n_cond * dh);
+      if (!c.dry && c.rc == PF_OK) c.rc = launch_attention(q2, C, kv, 2 * C, kv + C, 2 * C, att, C, B, nh, dh, hw, c.n_cond, c.s);
+      c.prof_end();
+      {
+        pf_conv_args a = conv_base(att, C, nullptr, 0, B, 1, hw, 1, c.w(t.o2w), C, t2);
+        a.bias = c.w(t.o2b); a.res = t1; a.ld_res = C;
+        c.conv(a, PF_K_GEMM);
+      }
+      std::swap(t1, t2);
+    }
+    // x = ff(LN3(x)) + x
+    c.ln(t1, M, C, mu, rs);
+    {
+      pf_conv_args a = conv_base(t1, C, nullptr, 0, B, 1, hw, 1, c.w(t.ff1w), 8 * C, ff);
+      a.prologue = 3; a.sc = c.w(t.n3g); a.sh = c.w(t.n3b); a.mean = mu; a.rstd = rs; a.bias = c.w(t.ff1b);
+      a.geglu = 1; a.ld_out = 4 * C;
+      c.conv(a, PF_K_GEMM);
+    }
+    {
+      pf_conv_args a = conv_base(ff, 4 * C, nullptr, 0, B, 1, hw, 1, c.w(t.ff2w), C, t2);
+      a.bias = c.w(t.ff2b); a.res = t1; a.ld_res = C;
+      c.conv(a, PF_K_GEMM);
+    }
+    std::swap(t0, t2);
+  }
+  {
+    pf_conv_args a = conv_base(t0, C, nullptr, 0, B, 1, hw, 1, c.w(L.pout_w), C, out);
+    a.bias = c.w(L.pout_b); a.res = x; a.ld_res = C;
+    c.conv(a, PF_K_GEMM);
+  }
+  return out;
+}
+
+static void small_launch(Ctx& c, int rc_in) { if (c.rc == PF_OK) c.rc = rc_in; }
+
+static int run(pf_unet* u, Ctx& c, const float* x, const int64_t* t, const float* cond, float* eps) {
+  const pf_unet_cfg& cfg = u->cfg;
+  const int B = c.B;
+  int H = cfg.img_h, W_ = cfg.img_w;
+  // time embedding and every ResBlock's additive time bias
+  float* tsilu = c.palloc((size_t)B * u->d_t);
+  float* tb_all = c.palloc((size_t)B * u->sum_emb);
+  c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_time_embed(t, c.w(u->te_w0), c.w(u->te_b0), c.w(u->te_w2), c.w(u->te_b2), tsilu, B, cfg.channels, u->d_t, c.s)); c.prof_end();
+  c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_matvec(tsilu, u->d_t, c.w(u->emb_w), c.w(u->emb_b), tb_all, u->sum_emb, B, u->sum_emb, u->d_t, c.s)); c.prof_end();
+  // n_cond == 1: per-sample cross-attention bias to_out(to_v(c)) for every transformer block
+  float* cross_all = nullptr;
+  if (c.n_cond == 1) {
+    const int ntb = u->n_st * cfg.tf_layers;
+    int cmax = 0;
+    auto each_st = [&](auto&& fn) {
+      for (auto& b : u->in_blocks) for (auto& L : b.layers) if (L.kind == 2) fn(L);
+      for (auto& L : u->mid.layers) if (L.kind == 2) fn(L);
+      for (auto& b : u->out_blocks) for (auto& L : b.layers) if (L.kind == 2) fn(L);
+    };
+    each_st([&](const Layer& L) { cmax = std::max(cmax, L.cin); });
+    c.cross_cmax = cmax;
+    cross_all = c.palloc((size_t)ntb * B * cmax);
+    float* vtmp = c.palloc((size_t)B * cmax);
+    each_st([&](const Layer& L) {
+      const int C = L.cin;
+      for (size_t i = 0; i < L.tbs.size(); ++i) {
+        float* dst = c.dry ? nullptr : cross_all + ((size_t)(L.st_index * cfg.tf_layers + i) * B) * cmax;
+        c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_matvec(cond, cfg.d_cond, c.w(L.tbs[i].v2raw), nullptr, vtmp, C, B, C, cfg.d_cond, c.s)); c.prof_end();
+        c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_matvec(vtmp, C, c.w(L.tbs[i].o2raw), c.w(L.tbs[i].o2b), dst, C, B, C, C, c.s)); c.prof_end();
+      }
+    });
+  }
+
+  std::vector<const float*> skips;
+  std::vector<int> skip_c;
+  const float* cur = nullptr;
+  int cur_c = 0;
+  auto run_layers = [&](const Block& b, const float* in0, int c0, const float* in1, int c1) {
+    const float* a0 = in0; int ac0 = c0; const float* a1 = in1; int ac1 = c1;
+    for (const Layer& L : b.layers) {
+      float* o = nullptr;
+      switch (L.kind) {
+        case 0: {
+          o = c.palloc((size_t)B * H * W_ * L.cout);
+          c.prof_begin(PF_K_SMALL, 2.0 * B * H * W_ * 9.0 * L.cin * L.cout);
+          if (!c.dry) small_launch(c, launch_conv_in(x, c.w(u->in_w), c.w(u->in_b), o, B, L.cin, L.cout, H, W_, c.s));
+          c.prof_end();
+          break;
+        }
+        case 1: o = run_res(c, L, a0, ac0, a1, ac1, H, W_, tb_all); break;
+        case 2: o = run_st(c, L, a0, H, W_, cond, cross_all); break;
+        case 3: {
+          o = c.palloc((size_t)B * (H / 2) * (W_ / 2) * L.cout);
+          pf_conv_args a = conv_base(a0, ac0, nullptr, 0, B, H, W_, 3, c.w(L.w1), L.cout, o);
+          a.stride = 2; a.bias = c.w(L.b1);
+          c.conv(a, PF_K_CONV3);
+          H /= 2; W_ /= 2;
+          break;
+        }
+        case 4: {
+          o = c.palloc((size_t)B * (H * 2) * (W_ * 2) * L.cout);
+          pf_conv_args a = conv_base(a0, ac0, nullptr, 0, B, H, W_, 3, c.w(L.w1), L.cout, o);
+          a.ups = 1; a.bias = c.w(L.b1);
+          c.conv(a, PF_K_CONV3);
+          H *= 2; W_ *= 2;
+          break;
+        }
+      }
+      a0 = o; ac0 = L.cout; a1 = nullptr; ac1 = 0;
+    }
+    cur = a0; cur_c = ac0;
+  };
+
+  for (const Block& b : u->in_blocks) {
+    run_layers(b, cur, cur_c, nullptr, 0);
+    skips.push_back(cur); skip_c.push_back(cur_c);
+  }
+  run_layers(u->mid, cur, cur_c, nullptr, 0);
+  for (const Block& b : u->out_blocks) {
+    const float* sk = skips.back(); const int sc_ = skip_c.back();
+    skips.pop_back(); skip_c.pop_back();
+    run_layers(b, cur, cur_c, sk, sc_);  // channel order [x, skip] (unet.py:192)
+  }
+  // out: GN + SiLU + conv3x3 -> NCHW
+  c.treset();
+  float* sc = c.talloc((size_t)B * cur_c); float* sh = c.talloc((size_t)B * cur_c);
+  c.gn(cur, cur_c, nullptr, 0, H * W_, 1e-5f, u->out_g, u->out_b, sc, sh);
+  c.prof_begin(PF_K_SMALL, 2.0 * B * H * W_ * 9.0 * cur_c * cfg.out_channels);
+  if (!c.dry) small_launch(c, launch_conv_out(cur, sc, sh, c.w(u->out_w), c.w(u->out_bias), eps, B, cur_c, cfg.out_channels, H, W_, c.s));
+  c.prof_end();
+  return c.rc;
+}
+
+static void plan_sizes(pf_unet* u, int batch, int n_cond, size_t* persist, size_t* temp, int* launches) {
+  Ctx c{};
+  c.u = u; c.dry = true; c.B = batch; c.n_cond = n_cond; c.rc = PF_OK;
+  run(u, c, nullptr, nullptr, nullptr, nullptr);
+  *persist = align_up(c.persist_max, 4096);
+  *temp = align_up(c.temp_max, 4096);
+  if (launches) *launches = c.n_launch;
+}
+
+}  // namespace pf
+
+extern "C" {
+
+int pf_version(void) { return 100; }
+const char* pf_last_error(void) { return g_err.c_str(); }
+
+int pf_unet_create(const pf_unet_cfg* cfg, pf_unet** out) {
+  PF_REQUIRE(cfg && out, "pf_unet_create: null argument");
+  std::unique_ptr<pf_unet> u(new pf_unet());
+  u->cfg = *cfg;
+  int rc = build(u.get());
+  if (rc != PF_OK) return rc;
+  *out = u.release();
+  return PF_OK;
+}
+
+void pf_unet_destroy(pf_unet* u) {
+  if (!u) return;
+  for (auto e : u->ev) (void)hipEventDestroy(e);
+  delete u;
+}
+
+size_t pf_unet_weight_bytes(const pf_unet* u) { return u ? u->blob_floats * sizeof(float) : 0; }
+int pf_unet_n_params(const pf_unet* u) { return u ? (int)u->params.size() : 0; }
+
+int pf_unet_param_info(const pf_unet* u, int i, char* key_buf, size_t key_buf_len, int64_t shape[4], int* ndim) {
+  PF_REQUIRE(u && i >= 0 && i < (int)u->params.size() && key_buf && shape && ndim, "pf_unet_param_info: bad arguments");
+  const ParamSpec& ps = u->params[i];
+  snprintf(key_buf, key_buf_len, "%s", ps.key.c_str());
+  *ndim = (int)ps.shape.size();
+  for (int d = 0; d < 4; ++d) shape[d] = d < *ndim ? ps.shape[d] : 1;
+  return PF_OK;
+}
+
+int pf_unet_pack_param(pf_unet* u, const char* key, const float* src, const int64_t* shape, int ndim, void* host_blob) {
+  PF_REQUIRE(u && key && src && shape && host_blob, "pf_unet_pack_param: null argument");
+  auto it = u->index.find(key);
+  if (it == u->index.end()) return set_error(PF_ENOTFOUND, "unexpected key '%s' (not a parameter of this UNet)", key);
+  ParamSpec& ps = u->params[it->second];
+  bool ok = ndim == (int)ps.shape.size();
+  for (int d = 0; ok && d < ndim; ++d) ok = shape[d] == ps.shape[d];
+  if (!ok) {
+    std::string want, got;
+    for (auto s : ps.shape) want += std::to_string(s) + ",";
+    for (int d = 0; d < ndim; ++d) got += std::to_string(shape[d]) + ",";
+    return set_error(PF_EINVAL, "size mismatch for '%s': expected [%s] got [%s]", key, want.c_str(), got.c_str());
+  }
+  pack_one(ps, src, (float*)host_blob);
+  ps.packed = true;
+  return PF_OK;
+}
+
+int pf_unet_pack_missing(const pf_unet* u, char* buf, size_t buf_len) {
+  if (!u) return set_error(PF_EINVAL, "null handle");
+  int n = 0;
+  for (const ParamSpec& ps : u->params)
+    if (!ps.packed) {
+      if (n == 0 && buf && buf_len) snprintf(buf, buf_len, "%s", ps.key.c_str());
+      ++n;
+    }
+  return n;
+}
+
+int pf_unet_bind_weights(pf_unet* u, const void* dev_blob) {
+  PF_REQUIRE(u && dev_blob, "pf_unet_bind_weights: null argument");
+  PF_REQUIRE(((uintptr_t)dev_blob & 255) == 0, "pf_unet_bind_weights: blob must be 256-byte aligned");
+  u->wdev = (const float*)dev_blob;
+  return PF_OK;
+}
+
+size_t pf_unet_workspace_bytes(const pf_unet* u, int batch, int n_cond) {
+  if (!u || batch <= 0 || n_cond <= 0) return 0;
+  size_t p, t;
+  plan_sizes(const_cast<pf_unet*>(u), batch, n_cond, &p, &t, nullptr);
+  return p + t;
+}
+
+int pf_unet_n_launches(const pf_unet* u, int batch, int n_cond) {
+  if (!u || batch <= 0 || n_cond <= 0) return 0;
+  size_t p, t; int n = 0;
+  plan_sizes(const_cast<pf_unet*>(u), batch, n_cond, &p, &t, &n);
+  return n;
+}
+
+int pf_unet_forward(pf_unet* u, const float* x, const int64_t* t, const float* cond, int batch, int n_cond, float* eps,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  PF_REQUIRE(u && x && t && cond && eps && workspace, "pf_unet_forward: null argument");
+  PF_REQUIRE(batch > 0 && n_cond > 0, "pf_unet_forward: batch and n_cond must be positive");
+  if (!u->wdev) return set_error(PF_ESTATE, "pf_unet_forward: weights not bound (call pf_unet_bind_weights)");
+  PF_REQUIRE(n_cond == 1 || u->cfg.d_cond % 32 == 0, "pf_unet_forward: n_cond > 1 needs d_cond %% 32 == 0");
+  PF_REQUIRE(((uintptr_t)workspace & 255) == 0, "pf_unet_forward: workspace must be 256-byte aligned");
+  size_t p, tmp;
+  plan_sizes(u, batch, n_cond, &p, &tmp, nullptr);
+  if (workspace_bytes < p + tmp) return set_error(PF_EINVAL, "pf_unet_forward: workspace too small (%zu < %zu)", workspace_bytes, p + tmp);
+  Ctx c{};
+  c.u = u; c.s = (hipStream_t)stream; c.dry = false; c.base = (char*)workspace; c.temp_base = p;
+  c.B = batch; c.n_cond = n_cond; c.W = u->wdev; c.rc = PF_OK;
+  if (u->profiling) { u->n_prof = 0; u->pkind.clear(); u->pflops.clear(); }
+  return run(u, c, x, t, cond, eps);
+}
+
+int pf_unet_set_profiling(pf_unet* u, int enabled) {
+  PF_REQUIRE(u, "null handle");
+  u->profiling = enabled != 0;
+  u->n_prof = 0; u->pkind.clear(); u->pflops.clear();
+  return PF_OK;
+}
+
+int pf_unet_profile_read(pf_unet* u, int* kind, float* ms, double* flops, int capacity) {
+  PF_REQUIRE(u && kind && ms && flops, "pf_unet_profile_read: null argument");
+  const int n = u->n_prof < capacity ? u->n_prof : capacity;
+  for (int i = 0; i < n; ++i) {
+    PF_CHECK_HIP(hipEventSynchronize(u->ev[(size_t)i * 2 + 1]));
+    float v = 0.f;
+    PF_CHECK_HIP(hipEventElapsedTime(&v, u->ev[(size_t)i * 2], u->ev[(size_t)i * 2 + 1]));
+    kind[i] = u->pkind[i]; ms[i] = v; flops[i] = u->pflops[i];
+  }
+  return n;
+}
+
+size_t pf_packed_gemm_weight_floats(int n, int k, int taps) { return pf_unet::gemm_floats(taps, k, n); }
+int pf_pack_gemm_weight(const float* w, int n, int k, int taps, float* dst) {
+  PF_REQUIRE(w && dst && n > 0 && k > 0 && k % 4 == 0 && (taps == 1 || taps == 9), "pf_pack_gemm_weight: bad arguments");
+  memset(dst, 0, pf_unet::gemm_floats(taps, k, n) * sizeof(float));
+  pack_gemm(dst, w, n, k, taps, (n + 63) / 64 * 64, 0);
+  return PF_OK;
+}
+
+int pf_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batch, int hw, int groups, float eps,
+                      const float* gamma, const float* beta, float* scale, float* shift, void* scratch, size_t scratch_bytes,
+                      void* stream) {
+  return launch_gn_scale_shift(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, scale, shift, scratch, scratch_bytes, (hipStream_t)stream);
+}
+int pf_ln_stats(const float* x, int rows, int c, float eps, float* mean, float* rstd, void* stream) {
+  return launch_ln_stats(x, rows, c, eps, mean, rstd, (hipStream_t)stream);
+}
+int pf_conv2d(const pf_conv_args* a, void* stream) {
+  PF_REQUIRE(a, "pf_conv2d: null argument");
+  return launch_conv(*a, (hipStream_t)stream);
+}
+int pf_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int batch,
+                 int n_heads, int d_head, int lq, int lk, void* stream) {
+  PF_REQUIRE(q && k && v && o, "pf_attention: null argument");
+  return launch_attention(q, ldq, k, ldk, v, ldv, o, ldo, batch, n_heads, d_head, lq, lk, (hipStream_t)stream);
+}
+
+int pf_cfg_combine(const float* eps2, float scale, float* eps, size_t n, void* stream) { return launch_cfg_combine(eps2, scale, eps, n, (hipStream_t)stream); }
+int pf_ddpm_step(const float* x, const float* eps, const float* noise_p, const float* noise_q, const float* orig, const float* mask,
+                 const pf_ddpm_coef* c, float* x_out, size_t n, void* stream) {
+  PF_REQUIRE(c, "pf_ddpm_step: null coefficients");
+  return launch_ddpm_step(x, eps, noise_p, noise_q, orig, mask, *c, x_out, n, (hipStream_t)stream);
+}
+int pf_axpby(const float* x, const float* noise, float a, float b, float* out, size_t n, void* stream) { return launch_axpby(x, noise, a, b, out, n, (hipStream_t)stream); }
+int pf_ddim_step(const float* x, const float* eps, const float* noise, const float* orig, const float* orig_noise, const float* mask,
+                 const pf_ddim_coef* c, float* x_out, size_t n, void* stream) {
+  PF_REQUIRE(c, "pf_ddim_step: null coefficients");
+  return launch_ddim_step(x, eps, noise, orig, orig_noise, mask, *c, x_out, n, (hipStream_t)stream);
+}
+int pf_randn(float* out, size_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, void* stream) {
+  return launch_randn(out, n, seed, stream_id, elem_offset, (hipStream_t)stream);
+}
+
+}  // extern "C"

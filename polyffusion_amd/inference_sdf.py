@@ -1,0 +1,366 @@
+"""Drop-in for the reference ``polyffusion/inference_sdf.py`` on the denoising path.
+
+Kept from the reference: the flag names (``inference_sdf.py:404-507``, typed properly - the
+reference leaves ``--ddim_steps``/``--ddim_eta`` as strings), the
+``params.yaml`` discovery rule (:518-532), model assembly (:536-557), checkpoint loading for the
+legacy ``.pt`` format (:702-716), ``Experiments.predict/generate/inpaint`` incl. the
+autoregressive 4-bar inpainting schedule (:202-303), ``get_autoreg_data`` (:121-129),
+``dummy_cond_input`` (:60-72) and ``get_mask`` (:132-193).
+
+Not rebuilt (out of the hot-path scope): dataset / MIDI readers, chord
+extraction, MIDI writers, Polydis comparison.  Conditions therefore come from ``--cond_npz`` (arrays
+``chord`` [B,32,36] and/or ``prmat`` [B,128,128], optional ``prmat2c`` for inpainting) or from the
+seeded synthetic generator (``--synthetic``); the result is written as ``.npy`` ([B,2,128,128] piano
+roll, or [2B,2,64,128] half-segments for ``--autoreg``).  ``--synthetic_weights`` replaces the
+checkpoint by the deterministic weight generator (no trained weights ship with the reference).
+"""
+from __future__ import annotations
+
+import os
+import random
+from argparse import ArgumentParser
+from datetime import datetime
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import synth
+from .model_sdf import ChordEncoder, Polyffusion_SDF, TextureEncoder
+from .params import Params, find_params, load_params, preset
+from .sampler import DDIMSampler, DiffusionSampler, SDFSampler
+from .unet import LatentDiffusion, UNetModel
+
+
+def _dev():
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def dummy_cond_input(length, params):
+    h, w = params.img_h, params.img_w
+    prmat2c = torch.zeros([length, 2, h, w], device=_dev())
+    chord = torch.zeros([length, params.chd_n_step, params.chd_input_dim], device=_dev()) if "chord" in params.cond_type else None
+    prmat = torch.zeros([length, h, w], device=_dev())
+    return prmat2c, None, chord, prmat
+
+
+def get_autoreg_data(data: torch.Tensor, split_dim: int = 1) -> torch.Tensor:
+    """(second half of item i, first half of item i+1): the half-shifted stream for odd runs."""
+    steps = data.shape[split_dim]
+    half_1, half_2 = data.split(steps // 2, dim=split_dim)
+    return torch.cat((half_2, half_1.roll(-1, dims=0)), dim=split_dim)
+
+
+def get_mask(orig: torch.Tensor, inpaint_type: str, bar_list=None) -> torch.Tensor:
+    """Inpainting masks (1 = keep the original).  Vectorised restatement of the reference's row loops."""
+    B = orig.shape[0]
+    if inpaint_type == "remaining":
+        return orig.clone()
+    if inpaint_type in ("below", "above"):
+        onset = orig[:, 0]
+        steps, pitches = onset.shape[1], onset.shape[2]
+        flat = onset.reshape(B * steps, pitches)
+        if inpaint_type == "below":
+            edge = flat.argmax(dim=1)            # lowest onset per step; 0 doubles as "no onset" (reference quirk)
+            sentinel = 0
+        else:
+            edge = (pitches - 1) - flat.flip(1).argmax(dim=1)
+            sentinel = pitches - 1               # "no onset" for the top edge
+        nz = edge.nonzero()                      # the reference tests `!= 0` for BOTH types (:145,:167)
+        if nz.numel() == 0:
+            raise IndexError("get_mask: no usable onsets in the original (the reference fails here too)")
+        first = int(nz[0, 0])
+        edge[:first] = edge[first]
+        # sequential rule of the reference: a "no onset" step copies the previous step, step 0 wraps to the last
+        if int(edge[0]) == sentinel:
+            edge[0] = edge[-1]
+        empty = edge == sentinel
+        empty[0] = False
+        idx = torch.arange(B * steps, device=orig.device)
+        last = torch.where(empty, torch.full_like(idx, -1), idx).cummax(0).values
+        edge = edge[last]
+        cols = torch.arange(pitches, device=orig.device)[None, :]
+        m = (cols >= edge[:, None]) if inpaint_type == "below" else (cols <= edge[:, None])
+        return m.to(orig.dtype).reshape(B, 1, steps, pitches).expand(-1, 2, -1, -1).contiguous()
+    if inpaint_type == "bars":
+        if bar_list is None:
+            raise ValueError("get_mask('bars') needs bar_list (the reference prompts on stdin)")
+        mask = torch.ones_like(orig)
+        for bar in bar_list:
+            mask[:, :, bar * 16: bar * 16 + 16, :] = 0
+        return mask
+    raise NotImplementedError(inpaint_type)
+
+
+class Experiments:
+    """``inference_sdf.py:196-400``.  ``t_idx`` replaces the reference's read of the module-global
+    ``args`` (ddim_steps-1 or n_steps-1); ``noise`` lets tests inject the start noise."""
+
+    def __init__(self, model_label, params, sampler: DiffusionSampler, t_idx: Optional[int] = None, repaint_n: int = 1):
+        self.model_label = model_label
+        self.params = params if isinstance(params, Params) else Params(params)
+        self.sampler = sampler
+        if t_idx is None:
+            t_idx = (len(sampler.time_steps) - 1) if isinstance(sampler, DDIMSampler) else self.params.n_steps - 1
+        self.t_idx = int(t_idx)
+        self.repaint_n = int(repaint_n)
+
+    @torch.no_grad()
+    def predict(self, cond: torch.Tensor, cond_mid: Optional[torch.Tensor] = None, uncond_scale=1.0, autoreg=False,
+                orig=None, mask=None, cond_concat=None, noise: Optional[torch.Tensor] = None):
+        p, dev = self.params, cond.device
+        B = cond.shape[0]
+        shape = [B, p.out_channels, p.img_h, p.img_w]
+        uncond_cond = -torch.ones([B, 1, p.d_cond], device=dev)
+        if orig is None or mask is None:
+            orig, mask = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
+        if noise is None:
+            noise = self.sampler.randn(shape, dev)
+        t_idx = self.t_idx
+        kw = dict(uncond_scale=uncond_scale, cond_concat=cond_concat, repaint_n=self.repaint_n)
+        if not autoreg:
+            xt = self.sampler.q_sample(orig, t_idx, noise)
+            return self.sampler.paint(xt, cond, t_idx, orig=orig, mask=mask, orig_noise=noise, uncond_cond=uncond_cond, **kw)
+        assert cond_mid is not None
+        half = p.img_h // 2
+        orig, mask = orig.clone(), mask.clone()  # edited in place below, like the reference's views
+        orig_mid, mask_mid, noise_mid = (get_autoreg_data(v, split_dim=2) for v in (orig, mask, noise))
+        uc = uncond_cond[0:1]
+        gen, new_half = [], None
+        for idx in range(B * 2 - 1):  # inpaint a 4-bar half each time
+            src = (cond_mid, orig_mid, mask_mid, noise_mid) if idx % 2 == 1 else (cond, orig, mask, noise)
+            c_s, o_s, m_s, n_s = (v[idx // 2: idx // 2 + 1] for v in src)
+            if idx != 0:
+                o_s[:, :, 0:half, :] = new_half
+                m_s[:, :, 0:half, :] = 1
+            xt = self.sampler.q_sample(o_s, t_idx, n_s)
+            x0 = self.sampler.paint(xt, c_s, t_idx, orig=o_s, mask=m_s, orig_noise=n_s, uncond_cond=uc, **kw)
+            if idx == 0:
+                gen.append(x0[:, :, 0:half, :])
+            new_half = x0[:, :, half:, :]
+            gen.append(new_half)
+        gen = torch.cat(gen, dim=0)
+        assert gen.shape[0] == B * 2
+        return gen
+
+    @torch.no_grad()
+    def predict_songs(self, cond: torch.Tensor, cond_mid: torch.Tensor, uncond_scale=1.0):
+        """Autoregressive generation batched ACROSS songs (config 5): cond/cond_mid are [S, B, 1, d_cond];
+        the 2B-1 runs stay sequential within a song but each run denoises all S songs at once.
+        Returns [S, 2B, C, H/2, W]."""
+        p, dev = self.params, cond.device
+        S, B = cond.shape[0], cond.shape[1]
+        shape = [S, p.out_channels, p.img_h, p.img_w]
+        half = p.img_h // 2
+        uc = -torch.ones([S, 1, p.d_cond], device=dev)
+        gen, new_half = [], None
+        for idx in range(B * 2 - 1):
+            c_s = (cond_mid if idx % 2 == 1 else cond)[:, idx // 2].contiguous()
+            o_s, m_s = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
+            n_s = self.sampler.randn(shape, dev)
+            if idx != 0:
+                o_s[:, :, 0:half, :] = new_half
+                m_s[:, :, 0:half, :] = 1
+            xt = self.sampler.q_sample(o_s, self.t_idx, n_s)
+            x0 = self.sampler.paint(xt, c_s, self.t_idx, orig=o_s, mask=m_s, orig_noise=n_s, uncond_scale=uncond_scale,
+                                    uncond_cond=uc, repaint_n=self.repaint_n)
+            if idx == 0:
+                gen.append(x0[:, :, 0:half, :])
+            new_half = x0[:, :, half:, :]
+            gen.append(new_half)
+        return torch.stack(gen, dim=1)
+
+    def _stamp(self, uncond_scale, autoreg, extra=""):
+        return (f"{self.model_label}{extra}[scale={uncond_scale}{',autoreg' if autoreg else ''}]"
+                f"_{datetime.now().strftime('%y-%m-%d_%H%M%S')}")
+
+    def generate(self, cond, cond_mid=None, uncond_scale=1.0, autoreg=False, no_output=False, cond_concat=None,
+                 output_dir="exp", **_ignored):
+        gen = self.predict(cond, cond_mid, uncond_scale, autoreg, cond_concat=cond_concat)
+        if not no_output:
+            os.makedirs(output_dir, exist_ok=True)
+            np.save(os.path.join(output_dir, self._stamp(uncond_scale, autoreg) + ".npy"), gen.cpu().numpy())
+        return gen
+
+    def inpaint(self, orig, inpaint_type, cond, cond_mid=None, autoreg=False, orig_noise=None, uncond_scale=1.0,
+                bar_list=None, no_output=False, cond_concat=None, output_dir="exp"):
+        mask = get_mask(orig, inpaint_type, bar_list).to(orig.device)
+        gen = self.predict(cond, cond_mid, uncond_scale, autoreg, orig, mask, cond_concat=cond_concat, noise=orig_noise)
+        if not no_output:
+            os.makedirs(output_dir, exist_ok=True)
+            np.save(os.path.join(output_dir, self._stamp(uncond_scale, autoreg, f"_inp{self.repaint_n}_{inpaint_type}") + ".npy"),
+                    gen.cpu().numpy())
+        return gen
+
+
+# --------------------------------------------------------------------------------------------- assembly
+def build_unet(params, device=None) -> UNetModel:
+    return UNetModel(in_channels=params.in_channels, out_channels=params.out_channels, channels=params.channels,
+                     attention_levels=params.attention_levels, n_res_blocks=params.n_res_blocks,
+                     channel_multipliers=params.channel_multipliers, n_heads=params.n_heads, tf_layers=params.tf_layers,
+                     d_cond=params.d_cond, img_h=params.img_h, img_w=params.img_w, device=device)
+
+
+def build_ldm(params, unet: UNetModel) -> LatentDiffusion:
+    return LatentDiffusion(linear_start=params.linear_start, linear_end=params.linear_end, n_steps=params.n_steps,
+                           latent_scaling_factor=params.latent_scaling_factor, autoencoder=None, unet_model=unet)
+
+
+def build_encoders(params, device=None):
+    chord_enc = txt_enc = None
+    if "chord" in params.cond_type and params.use_enc:
+        chord_enc = ChordEncoder(params.chd_input_dim, params.chd_hidden_dim, params.chd_z_dim, device)
+    if "txt" in params.cond_type and params.use_enc:
+        txt_enc = TextureEncoder(params.txt_emb_size, params.txt_hidden_dim, params.txt_z_dim, params.txt_num_channel, device)
+    return chord_enc, txt_enc
+
+
+def synthetic_model(params, seed: int = 0, device=None) -> Polyffusion_SDF:
+    """Whole model with deterministic synthetic weights (same generator as the golden vectors)."""
+    from .arch import UNetConfig
+    from .weights import synth_chord_encoder_state, synth_texture_encoder_state, synth_unet_state
+    unet = build_unet(params, device)
+    unet.load_state_dict(synth_unet_state(UNetConfig.from_params(params), seed))
+    chord_enc, txt_enc = build_encoders(params, device)
+    if chord_enc is not None:
+        chord_enc.load_state_dict(synth_chord_encoder_state(seed, params.chd_input_dim, params.chd_hidden_dim, params.chd_z_dim))
+    if txt_enc is not None:
+        txt_enc.load_state_dict(synth_texture_encoder_state(seed, params.txt_emb_size, params.txt_hidden_dim,
+                                                            params.txt_z_dim, params.txt_num_channel))
+    return Polyffusion_SDF(build_ldm(params, unet), params.cond_type, params.cond_mode, chord_enc=chord_enc, txt_enc=txt_enc)
+
+
+def encode_conditions(model: Polyffusion_SDF, params, chd, prmat, autoreg: bool):
+    cond_mid = None
+    if params.cond_type == "chord":
+        assert chd is not None
+        cond = model._encode_chord(chd)
+        if autoreg:
+            cond_mid = model._encode_chord(get_autoreg_data(chd))
+    elif params.cond_type == "txt":
+        assert prmat is not None
+        cond = model._encode_txt(prmat)
+        if autoreg:
+            cond_mid = model._encode_txt(get_autoreg_data(prmat))
+    elif params.cond_type == "chord+txt":
+        assert chd is not None and prmat is not None
+        n = min(chd.shape[0], prmat.shape[0])
+        chd, prmat = chd[:n], prmat[:n]
+        cond = torch.cat([model._encode_chord(chd), model._encode_txt(prmat)], dim=-1)
+        if autoreg:
+            cond_mid = torch.cat([model._encode_chord(get_autoreg_data(chd)), model._encode_txt(get_autoreg_data(prmat))], dim=-1)
+    else:
+        raise NotImplementedError(f"cond_type {params.cond_type!r} is outside the rebuilt path")
+    return cond, cond_mid
+
+
+def make_parser() -> ArgumentParser:
+    p = ArgumentParser(description="inference a Polyffusion model (MI355X-native denoising path)")
+    p.add_argument("--chkpt_path", help="the path of the checkpoint to be used")
+    p.add_argument("--custom_params_path", help="params yaml/json; default <chkpt>/../../params.yaml")
+    p.add_argument("--uncond_scale", type=float, default=1.0, help="unconditional scale for classifier-free guidance")
+    p.add_argument("--seed", type=int, help="use a specific seed for inference")
+    p.add_argument("--autoreg", action="store_true", help="autoregressively inpaint the music segments")
+    p.add_argument("--from_dataset", default=None, help="(not rebuilt) choose condition from a dataset")
+    p.add_argument("--from_midi", help="(not rebuilt) choose condition from a midi file")
+    p.add_argument("--from_midi2", help="(not rebuilt)")
+    p.add_argument("--inpaint_from_midi", help="(not rebuilt)")
+    p.add_argument("--inpaint_from_dataset", default=None, help="(not rebuilt)")
+    p.add_argument("--inpaint_pop909_use_track", help="(not rebuilt)")
+    p.add_argument("--inpaint_type", help="inpaint a song, type: {remaining, below, above, bars}")
+    p.add_argument("--ddim", action="store_true", help="whether to use DDIM sampler")
+    p.add_argument("--ddim_discretize", default="uniform", help="{uniform(default), quad}")
+    p.add_argument("--ddim_eta", type=float, default=0.0, help="ddim eta, default: 0.0")
+    p.add_argument("--ddim_steps", type=int, default=50, help="number of ddim sampling steps, default: 50")
+    p.add_argument("--repaint_n", type=int, default=1, help="n sampling steps in RePaint")
+    p.add_argument("--length", type=int, default=0, help="the generated length (in 8-bars)")
+    p.add_argument("--show_image", action="store_true", help="(ignored: no image writer on this path)")
+    p.add_argument("--chkpt_name", default="weights_best.pt")
+    p.add_argument("--num_generate", type=int, default=1, help="the number of samples to generate")
+    p.add_argument("--output_dir", default="exp", help="directory to store generated piano rolls")
+    # extensions of this build
+    p.add_argument("--params_preset", help="use a built-in params preset instead of a params.yaml (e.g. sdf_chd8bar)")
+    p.add_argument("--synthetic_weights", action="store_true", help="deterministic synthetic weights instead of a checkpoint")
+    p.add_argument("--synthetic", action="store_true", help="seeded synthetic chords / textures as conditions")
+    p.add_argument("--cond_npz", help="npz with arrays chord [B,32,36] and/or prmat [B,128,128] (and prmat2c for inpainting)")
+    p.add_argument("--bar_list", help="bars to inpaint for --inpaint_type bars, comma separated")
+    return p
+
+
+def main(argv=None):
+    args = make_parser().parse_args(argv)
+    for flag in ("from_dataset", "from_midi", "from_midi2", "inpaint_from_midi", "inpaint_from_dataset", "inpaint_pop909_use_track"):
+        if getattr(args, flag) is not None:
+            raise SystemExit(f"--{flag}: dataset / MIDI front ends are outside the rebuilt hot path; use --cond_npz or --synthetic")
+    if not torch.cuda.is_available():
+        raise SystemExit("inference_sdf needs an AMD GPU (no CPU fallback on this path)")
+    seed = args.seed if args.seed is not None else 0
+    torch.manual_seed(seed); np.random.seed(seed); random.seed(seed)
+
+    if args.params_preset is not None:
+        params = preset(args.params_preset)
+    else:
+        if args.chkpt_path is None and args.custom_params_path is None:
+            raise SystemExit("give --chkpt_path, --custom_params_path or --params_preset")
+        params = load_params(find_params(args.chkpt_path or ".", args.custom_params_path))
+    print(f"model_label: {params.model_name}")
+
+    if args.synthetic_weights:
+        model = synthetic_model(params, seed=0)
+    else:
+        path = args.chkpt_path
+        if path and os.path.exists(f"{path}/chkpts/{args.chkpt_name}"):
+            path = f"{path}/chkpts/{args.chkpt_name}"
+        if not path or not path.endswith(".pt"):
+            raise SystemExit("only legacy .pt checkpoints are supported on this path (Lightning .ckpt needs omegaconf)")
+        unet = build_unet(params)
+        chord_enc, txt_enc = build_encoders(params)
+        model = Polyffusion_SDF.load_trained(build_ldm(params, unet), path, params.cond_type, params.cond_mode,
+                                             chord_enc=chord_enc, txt_enc=txt_enc)
+
+    for i in range(args.num_generate):
+        print(f"Generating song {i} of {args.num_generate}")
+        length = args.length
+        chd = prmat = prmat2c_inp = None
+        if args.uncond_scale == 0.0 and args.cond_npz is None and not args.synthetic:
+            if length <= 0:
+                raise SystemExit("--length is required for unconditional generation")
+            _, _, chd, prmat = dummy_cond_input(length, params)
+        elif args.cond_npz is not None:
+            z = np.load(args.cond_npz)
+            chd = torch.from_numpy(z["chord"]).float().to(_dev()) if "chord" in z else None
+            prmat = torch.from_numpy(z["prmat"]).float().to(_dev()) if "prmat" in z else None
+            prmat2c_inp = torch.from_numpy(z["prmat2c"]).float().to(_dev()) if "prmat2c" in z else None
+        elif args.synthetic:
+            n = length if length > 0 else 1
+            chd = torch.from_numpy(synth.chords(n, seed + 100 + i)).to(_dev())
+            prmat = torch.from_numpy(synth.prmat(n, seed + 200 + i)).to(_dev())
+        else:
+            raise SystemExit("no condition source: use --cond_npz, --synthetic or --uncond_scale 0 --length N")
+
+        if args.ddim:
+            sampler = DDIMSampler(model.ldm, args.ddim_steps, args.ddim_discretize, args.ddim_eta, seed=seed + i)
+        else:
+            sampler = SDFSampler(model.ldm, seed=seed + i)
+        expmt = Experiments(params.model_name, params, sampler, repaint_n=args.repaint_n)
+        cond, cond_mid = encode_conditions(model, params, chd, prmat, args.autoreg)
+        if params.cond_mode == "uncond":
+            cond = -torch.ones_like(cond)
+        if length > 0:
+            cond = cond[:length]
+            cond_mid = cond_mid[:length] if cond_mid is not None else None
+        if args.inpaint_type is not None:
+            if prmat2c_inp is None:
+                raise SystemExit("--inpaint_type needs prmat2c in --cond_npz")
+            n = min(cond.shape[0], prmat2c_inp.shape[0])
+            bars = [int(v) for v in args.bar_list.split(",")] if args.bar_list else None
+            gen = expmt.inpaint(prmat2c_inp[:n], args.inpaint_type, cond[:n], None if cond_mid is None else cond_mid[:n],
+                                autoreg=args.autoreg, uncond_scale=args.uncond_scale, bar_list=bars, output_dir=args.output_dir)
+        else:
+            gen = expmt.generate(cond, cond_mid, uncond_scale=args.uncond_scale, autoreg=args.autoreg, output_dir=args.output_dir)
+        print(f"piano_roll: {tuple(gen.shape)}  onsets>0.5: {int((gen[:, 0] > 0.5).sum())}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -1,0 +1,183 @@
+"""Conditioning wrapper and frozen encoders (host mirrors backed by libpfhip.so).
+
+* ``ChordEncoder`` / ``TextureEncoder``: constructor argument order of the reference modules
+  (``dl_modules/chord_enc.py:6``, ``dl_modules/txt_enc.py:6``); ``encode_mean`` returns what the
+  reference reads from them, ``forward(x).mean``.
+* ``Polyffusion_SDF``: ``models/model_sdf.py`` - ``_encode_chord`` (:92-106), ``_encode_txt``
+  (:153-164) and ``load_trained`` (:59-84; legacy ``.pt`` with ``{"model": state_dict}``).
+* ``load_pretrained_chd_enc`` / ``load_pretrained_txt_enc``: the key-prefix remaps of
+  ``utils.py:48-86`` (``chord_enc.`` / ``rhy_encoder.``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+from typing import Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .unet import LatentDiffusion
+
+
+class _Encoder:
+    KIND = -1
+
+    def __init__(self, input_dim, emb_size, hidden_dim, z_dim, num_channel, device=None):
+        self._lib = _lib.load()
+        self.hidden_dim, self.z_dim = hidden_dim, z_dim
+        h = C.c_void_p()
+        _lib.check(self._lib.pf_encoder_create(self.KIND, input_dim, emb_size, hidden_dim, z_dim, num_channel, C.byref(h)),
+                   "pf_encoder_create")
+        self._h = h
+        self.device = torch.device(device) if device is not None else (
+            torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
+        self._blob = None
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.pf_encoder_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def pack_state_dict(self, state: Mapping[str, object]) -> torch.Tensor:
+        blob = torch.zeros(self._lib.pf_encoder_weight_bytes(self._h) // 4, dtype=torch.float32)
+        for key, val in state.items():
+            t = torch.as_tensor(np.asarray(val) if not isinstance(val, torch.Tensor) else val).detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+            _lib.check(self._lib.pf_encoder_pack_param(self._h, key.encode(), t.data_ptr(), shape, t.dim(), blob.data_ptr()),
+                       f"load_state_dict({key})")
+        buf = C.create_string_buffer(256)
+        if self._lib.pf_encoder_pack_missing(self._h, buf, 256):
+            raise RuntimeError(f"load_state_dict: missing key {buf.value.decode()}")
+        return blob
+
+    def bind_packed(self, blob_dev: torch.Tensor):
+        self._blob = blob_dev
+        self.device = blob_dev.device
+        _lib.check(self._lib.pf_encoder_bind_weights(self._h, blob_dev.data_ptr()))
+
+    def load_state_dict(self, state: Mapping[str, object]):
+        _lib.require_gpu()
+        self.bind_packed(self.pack_state_dict(state).to(self.device))
+        return self
+
+    def _run(self, x: torch.Tensor, n_step: int) -> torch.Tensor:
+        if self._blob is None:
+            raise RuntimeError("encoder weights not loaded")
+        x = x.contiguous().float()
+        B = x.shape[0]
+        nbytes = self._lib.pf_encoder_workspace_bytes(self._h, B)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        mu = torch.empty(B, self.z_dim, dtype=torch.float32, device=x.device)
+        _lib.check(self._lib.pf_encoder_forward(self._h, x.data_ptr(), B, n_step, mu.data_ptr(), self._ws.data_ptr(),
+                                                self._ws.numel(), _lib.current_stream()), "pf_encoder_forward")
+        return mu
+
+    def forward(self, x):
+        """Reference call shape: returns an object whose ``.mean`` is the encoder mean."""
+        return SimpleNamespace(mean=self.encode_mean(x))
+
+    __call__ = forward
+
+
+class ChordEncoder(_Encoder):
+    KIND = 0
+
+    def __init__(self, input_dim, hidden_dim, z_dim, device=None):
+        super().__init__(input_dim, 0, hidden_dim, z_dim, 0, device)
+
+    def encode_mean(self, chord: torch.Tensor) -> torch.Tensor:  # [B,T,input_dim] -> [B,z]
+        return self._run(chord, chord.shape[1])
+
+
+class TextureEncoder(_Encoder):
+    KIND = 1
+
+    def __init__(self, emb_size, hidden_dim, z_dim, num_channel=10, device=None):
+        super().__init__(0, emb_size, hidden_dim, z_dim, num_channel, device)
+
+    def encode_mean(self, pr: torch.Tensor) -> torch.Tensor:  # [B,32,128] -> [B,z]
+        assert tuple(pr.shape[1:]) == (32, 128), "texture encoder input must be [B,32,128]"
+        return self._run(pr, 8)
+
+
+def _strip(state: Mapping[str, object], part: str):
+    if "model" in state:
+        state = state["model"]
+    return {".".join(k.split(".")[1:]): v for k, v in state.items() if k.split(".")[0] == part}
+
+
+def load_pretrained_chd_enc(state: Mapping[str, object], input_dim, hidden_dim, z_dim, device=None) -> ChordEncoder:
+    """utils.py:48-69: keep the ``chord_enc.`` keys of a chd_8bar checkpoint."""
+    return ChordEncoder(input_dim, hidden_dim, z_dim, device).load_state_dict(_strip(state, "chord_enc"))
+
+
+def load_pretrained_txt_enc(state: Mapping[str, object], emb_size, hidden_dim, z_dim, num_channel, device=None) -> TextureEncoder:
+    """utils.py:72-86: keep the ``rhy_encoder.`` keys of a Polydis checkpoint."""
+    return TextureEncoder(emb_size, hidden_dim, z_dim, num_channel, device).load_state_dict(_strip(state, "rhy_encoder"))
+
+
+class Polyffusion_SDF:
+    def __init__(self, ldm: LatentDiffusion, cond_type, cond_mode="cond", chord_enc: Optional[ChordEncoder] = None,
+                 chord_dec=None, pnotree_enc=None, pnotree_dec=None, txt_enc: Optional[TextureEncoder] = None,
+                 concat_blurry=False, concat_ratio=1 / 8):
+        if pnotree_enc is not None or pnotree_dec is not None or chord_dec is not None:
+            raise NotImplementedError("pnotree / decoder modules are outside the denoising hot path (SURVEY.md 2 #12)")
+        self.ldm, self.cond_type, self.cond_mode = ldm, cond_type, cond_mode
+        self.chord_enc, self.txt_enc = chord_enc, txt_enc
+        self.concat_blurry, self.concat_ratio = concat_blurry, concat_ratio
+
+    @classmethod
+    def load_trained(cls, ldm, chkpt_fpath, cond_type, cond_mode="cond", chord_enc=None, chord_dec=None,
+                     pnotree_enc=None, pnotree_dec=None, txt_enc=None):
+        """Legacy ``.pt`` checkpoint: ``{"model": state_dict}`` with ``ldm.eps_model.*``, ``chord_enc.*``,
+        ``txt_enc.*`` keys and recomputable schedule vectors ``ldm.{alpha,beta,alpha_bar,sigma2}``."""
+        model = cls(ldm, cond_type, cond_mode, chord_enc, chord_dec, pnotree_enc, pnotree_dec, txt_enc)
+        ck = torch.load(chkpt_fpath, map_location="cpu", weights_only=True)
+        model.load_state_dict(ck["model"] if "model" in ck else ck)
+        return model
+
+    def load_state_dict(self, state: Mapping[str, object]):
+        unet, ce, te = {}, {}, {}
+        for k, v in state.items():
+            if k.startswith("ldm.eps_model."):
+                unet[k[len("ldm.eps_model."):]] = v
+            elif k.startswith("chord_enc."):
+                ce[k[len("chord_enc."):]] = v
+            elif k.startswith("txt_enc."):
+                te[k[len("txt_enc."):]] = v
+            elif k in ("ldm.alpha", "ldm.beta", "ldm.alpha_bar", "ldm.sigma2"):
+                continue  # recomputed from the params (latent_diffusion.py:90-103)
+            elif k.split(".")[0] in ("chord_dec", "pnotree_enc", "pnotree_dec"):
+                continue  # decode/debug-only modules
+            else:
+                raise RuntimeError(f"unexpected key in checkpoint: {k}")
+        self.ldm.eps_model.load_state_dict(unet)
+        if self.chord_enc is not None and ce:
+            self.chord_enc.load_state_dict(ce)
+        if self.txt_enc is not None and te:
+            self.txt_enc.load_state_dict(te)
+        return self
+
+    def eval(self):
+        return self
+
+    def _encode_chord(self, chord: torch.Tensor) -> torch.Tensor:
+        if self.chord_enc is not None:
+            return self.chord_enc(chord).mean.unsqueeze(1)  # [B,1,512]
+        return torch.reshape(chord, (-1, 1, chord.shape[1] * chord.shape[2]))
+
+    def _encode_txt(self, prmat: torch.Tensor) -> torch.Tensor:
+        if self.txt_enc is None:
+            return prmat
+        B = prmat.shape[0]
+        # the four 2-bar segments of every sample go through the encoder as ONE batch of 4B rows;
+        # [B,128,128] -> [B*4,32,128] is a pure view and the means come back as [B, 4*z] = cat(dim=-1)
+        segs = prmat.contiguous().view(B * 4, 32, prmat.shape[2])
+        return self.txt_enc(segs).mean.view(B, 1, -1)

@@ -1,0 +1,190 @@
+"""Host mirror of the reference denoiser objects, backed by libpfhip.so.
+
+``UNetModel`` keeps the reference constructor surface (keyword names of
+``stable_diffusion/model/unet.py:35-47``), ingests weights by the reference
+``state_dict`` key names and evaluates ``forward(x, t, cond)`` with the same
+argument meaning (``unet.py:171-196``) - but every FLOP runs in the HIP kernels of
+``csrc/``.  ``LatentDiffusion`` mirrors ``stable_diffusion/latent_diffusion.py``
+(schedule at :90-103, ``forward`` at :138-147) for the attributes the samplers use.
+
+PyTorch is plumbing here: device buffers, the current stream and (for multi-GPU)
+the RCCL broadcast of the packed weight blob.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, List, Mapping, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .arch import UNetConfig
+
+
+class UNetModel:
+    def __init__(self, *, in_channels: int, out_channels: int, channels: int, n_res_blocks: int,
+                 attention_levels: Iterable[int], channel_multipliers: Iterable[int], n_heads: int,
+                 tf_layers: int = 1, d_cond: int = 768, img_h: int = 128, img_w: int = 128,
+                 device: Optional[torch.device] = None):
+        self.cfg = UNetConfig(in_channels, out_channels, channels, n_res_blocks, tuple(attention_levels),
+                              tuple(channel_multipliers), n_heads, tf_layers, d_cond)
+        self.img_h, self.img_w = int(img_h), int(img_w)
+        self.channels = channels
+        self._lib = _lib.load()
+        c = _lib.UNetCfg()
+        c.in_channels, c.out_channels, c.channels, c.n_res_blocks = in_channels, out_channels, channels, n_res_blocks
+        c.n_attention_levels = len(self.cfg.attention_levels)
+        for i, v in enumerate(self.cfg.attention_levels):
+            c.attention_levels[i] = v
+        c.n_levels = len(self.cfg.channel_multipliers)
+        for i, v in enumerate(self.cfg.channel_multipliers):
+            c.channel_multipliers[i] = v
+        c.n_heads, c.tf_layers, c.d_cond, c.img_h, c.img_w = n_heads, tf_layers, d_cond, self.img_h, self.img_w
+        h = C.c_void_p()
+        _lib.check(self._lib.pf_unet_create(C.byref(c), C.byref(h)), "pf_unet_create")
+        self._h = h
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()) \
+            if torch.cuda.is_available() else None
+        self._blob_host: Optional[torch.Tensor] = None
+        self._blob_dev: Optional[torch.Tensor] = None
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_key: Tuple[int, int] = (0, 0)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.pf_unet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- weights --------------------------------------------------------------------------------
+    def param_shapes(self) -> "Dict[str, Tuple[int, ...]]":
+        out = {}
+        buf = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        nd = C.c_int()
+        for i in range(self._lib.pf_unet_n_params(self._h)):
+            _lib.check(self._lib.pf_unet_param_info(self._h, i, buf, 256, shape, C.byref(nd)))
+            out[buf.value.decode()] = tuple(int(shape[d]) for d in range(nd.value))
+        return out
+
+    def pack_state_dict(self, state: Mapping[str, object], strict: bool = True) -> torch.Tensor:
+        """Repack reference-named tensors into the kernel-friendly host blob (no GPU needed)."""
+        nbytes = self._lib.pf_unet_weight_bytes(self._h)
+        blob = torch.zeros(nbytes // 4, dtype=torch.float32)
+        for key, val in state.items():
+            t = torch.as_tensor(np.asarray(val) if not isinstance(val, torch.Tensor) else val).detach().to("cpu", torch.float32).contiguous()
+            shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+            rc = self._lib.pf_unet_pack_param(self._h, key.encode(), t.data_ptr(), shape, t.dim(), blob.data_ptr())
+            if rc == -2 and not strict:
+                continue
+            _lib.check(rc, f"load_state_dict({key})")
+        buf = C.create_string_buffer(256)
+        missing = self._lib.pf_unet_pack_missing(self._h, buf, 256)
+        if missing:
+            raise RuntimeError(f"load_state_dict: {missing} missing key(s), first: {buf.value.decode()}")
+        self._blob_host = blob
+        return blob
+
+    def weight_bytes(self) -> int:
+        return int(self._lib.pf_unet_weight_bytes(self._h))
+
+    def bind_packed(self, blob_dev: torch.Tensor):
+        """Attach a packed blob that already lives on the GPU (e.g. received by RCCL broadcast)."""
+        assert blob_dev.is_cuda and blob_dev.dtype == torch.float32 and blob_dev.numel() * 4 == self.weight_bytes()
+        self._blob_dev = blob_dev
+        self.device = blob_dev.device
+        _lib.check(self._lib.pf_unet_bind_weights(self._h, blob_dev.data_ptr()), "pf_unet_bind_weights")
+
+    def load_state_dict(self, state: Mapping[str, object], strict: bool = True):
+        """Reference-compatible weight ingestion (keys relative to ``eps_model``)."""
+        _lib.require_gpu()
+        blob = self.pack_state_dict(state, strict)
+        self.bind_packed(blob.to(self.device))
+        return self
+
+    def eval(self):
+        return self
+
+    # ---- forward --------------------------------------------------------------------------------
+    def workspace(self, batch: int, n_cond: int) -> torch.Tensor:
+        if self._ws is None or self._ws_key != (batch, n_cond):
+            nbytes = self._lib.pf_unet_workspace_bytes(self._h, batch, n_cond)
+            if self._ws is None or self._ws.numel() < nbytes:
+                self._ws = None
+                self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_key = (batch, n_cond)
+        return self._ws
+
+    def forward(self, x: torch.Tensor, time_steps: torch.Tensor, cond: torch.Tensor, out: Optional[torch.Tensor] = None):
+        if self._blob_dev is None:
+            raise RuntimeError("UNetModel.forward: weights not loaded")
+        B = x.shape[0]
+        if tuple(x.shape[1:]) != (self.cfg.in_channels, self.img_h, self.img_w):
+            raise RuntimeError(f"UNetModel.forward: x has shape {tuple(x.shape)}, expected [B,{self.cfg.in_channels},{self.img_h},{self.img_w}]")
+        if cond.dim() != 3 or cond.shape[0] != B or cond.shape[2] != self.cfg.d_cond:
+            raise RuntimeError(f"UNetModel.forward: cond has shape {tuple(cond.shape)}, expected [B,n_cond,{self.cfg.d_cond}]")
+        x = x.contiguous().float()
+        cond = cond.contiguous().float()
+        t = time_steps.to(torch.int64).contiguous()
+        n_cond = cond.shape[1]
+        ws = self.workspace(B, n_cond)
+        if out is None:
+            out = torch.empty(B, self.cfg.out_channels, self.img_h, self.img_w, dtype=torch.float32, device=x.device)
+        _lib.check(self._lib.pf_unet_forward(self._h, x.data_ptr(), t.data_ptr(), cond.data_ptr(), B, n_cond,
+                                             out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream()),
+                   "pf_unet_forward")
+        return out
+
+    __call__ = forward
+
+    # ---- profiling ------------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        _lib.check(self._lib.pf_unet_set_profiling(self._h, int(on)))
+
+    def read_profile(self) -> List[Tuple[int, float, float]]:
+        cap = 4096
+        kind = (C.c_int * cap)()
+        ms = (C.c_float * cap)()
+        fl = (C.c_double * cap)()
+        n = _lib.check(self._lib.pf_unet_profile_read(self._h, kind, ms, fl, cap))
+        return [(kind[i], ms[i], fl[i]) for i in range(n)]
+
+    def n_launches(self, batch: int, n_cond: int = 1) -> int:
+        return int(self._lib.pf_unet_n_launches(self._h, batch, n_cond))
+
+
+class LatentDiffusion:
+    """Mirror of ``stable_diffusion/latent_diffusion.py:LatentDiffusion`` without an autoencoder
+    (``inference_sdf.py:537`` passes ``autoencoder=None``)."""
+
+    def __init__(self, unet_model: UNetModel, autoencoder=None, latent_scaling_factor: float = 0.18215,
+                 n_steps: int = 1000, linear_start: float = 0.00085, linear_end: float = 0.012):
+        if autoencoder is not None:
+            raise NotImplementedError("the Polyffusion path runs without a latent autoencoder")
+        self.eps_model = unet_model
+        self.first_stage_model = None
+        self.latent_scaling_factor = latent_scaling_factor
+        self.n_steps = n_steps
+        # sqrt-linear schedule computed in float64 then cast (latent_diffusion.py:90-103)
+        beta = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_steps, dtype=torch.float64) ** 2
+        alpha = 1.0 - beta
+        alpha_bar = torch.cumprod(alpha, dim=0)
+        self.alpha = alpha.to(torch.float32)
+        self.beta = beta.to(torch.float32)
+        self.alpha_bar = alpha_bar.to(torch.float32)
+        self.sigma2 = self.beta
+
+    @property
+    def device(self):
+        return self.eps_model.device
+
+    def eval(self):
+        return self
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, context: torch.Tensor):
+        return self.eps_model(x, t, context)
+
+    __call__ = forward

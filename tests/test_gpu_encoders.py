@@ -1,0 +1,50 @@
+"""Condition-encoder parity (-m gpu) against golden vectors from the real reference modules."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import encoders_ref, unet_ref  # noqa: E402
+from polyffusion_amd import _lib, synth  # noqa: E402
+from polyffusion_amd.model_sdf import ChordEncoder, Polyffusion_SDF, TextureEncoder  # noqa: E402
+from polyffusion_amd.weights import synth_chord_encoder_state, synth_texture_encoder_state  # noqa: E402
+
+
+def test_encoders_vs_reference_golden(golden):
+    _lib.require_gpu()
+    g = golden("encoders.npz")
+    ce = ChordEncoder(36, 512, 512).load_state_dict(synth_chord_encoder_state(0))
+    te = TextureEncoder(256, 1024, 256, 10).load_state_dict(synth_texture_encoder_state(0))
+    m = Polyffusion_SDF(None, "chord+txt", chord_enc=ce, txt_enc=te)
+    zc = m._encode_chord(torch.from_numpy(synth.chords(3, int(g["chord_seed"]))).cuda())
+    zt = m._encode_txt(torch.from_numpy(synth.prmat(3, int(g["prmat_seed"]))).cuda())
+    assert zc.shape == (3, 1, 512) and zt.shape == (3, 1, 1024)
+    assert np.abs(zc.cpu().numpy() - g["z_chord"]).max() < 1e-4
+    assert np.abs(zt.cpu().numpy() - g["z_txt"]).max() < 1e-4
+
+
+def test_encoders_vs_oracle_other_batches():
+    """Ragged batch sizes (1, 9, 17 rows: partial mat-vec row blocks) and a short chord sequence."""
+    wc_np, wt_np = synth_chord_encoder_state(5), synth_texture_encoder_state(5)
+    ce = ChordEncoder(36, 512, 512).load_state_dict(wc_np)
+    te = TextureEncoder(256, 1024, 256, 10).load_state_dict(wt_np)
+    wc, wt = unet_ref.to_torch(wc_np), unet_ref.to_torch(wt_np)
+    for B in (1, 9, 17):
+        ch = torch.from_numpy(synth.chords(B, 40 + B))
+        ref = encoders_ref.chord_encoder_mean(wc, ch)
+        assert (ce(ch.cuda()).mean.cpu() - ref).abs().max() < 1e-4
+    ch = torch.from_numpy(synth.chords(2, 1, n_step=8))
+    assert (ce(ch.cuda()).mean.cpu() - encoders_ref.chord_encoder_mean(wc, ch)).abs().max() < 1e-4
+    pr = torch.from_numpy(synth.prmat(2, 3))
+    ref = encoders_ref.encode_txt(wt, pr)
+    got = Polyffusion_SDF(None, "txt", txt_enc=te)._encode_txt(pr.cuda()).cpu()
+    assert (got - ref).abs().max() < 1e-4
+
+
+def test_vanilla_conditions_pass_through():
+    m = Polyffusion_SDF(None, "chord")
+    ch = torch.from_numpy(synth.chords(2, 1))
+    assert m._encode_chord(ch).shape == (2, 1, 32 * 36)
+    pr = torch.from_numpy(synth.prmat(2, 1))
+    assert m._encode_txt(pr) is pr

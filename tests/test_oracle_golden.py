@@ -14,7 +14,7 @@ from polyffusion_amd.weights import (synth_chord_encoder_state, synth_texture_en
                                      synth_unet_state)
 
 SMALL = UNetConfig(in_channels=2, out_channels=2, channels=32, n_res_blocks=1, attention_levels=(1,),
-                   channel_multipliers=(1, 2), n_heads=2, tf_layers=1, d_cond=16)
+                   channel_multipliers=(1, 2), n_heads=2, tf_layers=1, d_cond=32)
 LIN = (0.00085, 0.012)
 TOL = 1e-5
 
@@ -90,7 +90,7 @@ def test_single_steps(golden):
             assert maxabs(p0, g[f"ddim_{tag}_predx0_{idx}"]) <= 1e-6 * sc
             assert maxabs(d.q_sample(x, idx, nz), g[f"ddim_{tag}_q_{idx}"]) <= 1e-6
     toy = lambda x_, t_, c_: x_ * c_.mean(dim=(1, 2))[:, None, None, None] + t_[:, None, None, None].float() * 1e-3
-    cc, uc, t7 = torch.from_numpy(g["cfg_c"]), -torch.ones(2, 1, 16), torch.tensor([7, 7])
+    cc, uc, t7 = torch.from_numpy(g["cfg_c"]), -torch.ones(2, 1, 32), torch.tensor([7, 7])
     for sc in (0.0, 1.0, 5.0):
         assert maxabs(sampler_ref.get_eps(toy, x, t7, cc, sc, uc), g[f"cfg_eps_{sc}"]) <= 1e-6
 
@@ -110,7 +110,7 @@ def test_trajectories(golden):
     g = golden("trajectories.npz")
     model = small_model()
     cond, start, orig, mask = (torch.from_numpy(g[k]) for k in ("cond", "start_noise", "orig", "mask"))
-    uc = -torch.ones(2, 1, 16)
+    uc = -torch.ones(2, 1, 32)
     z = torch.zeros_like(start)
     tape = _Tape(g["ddpm_gen_tape"])
     s = sampler_ref.SDFSamplerRef(model, 1000, *LIN, noise_fn=tape)

@@ -32,7 +32,7 @@ from polyffusion_amd.weights import (  # noqa: E402
 from polyffusion_amd import synth  # noqa: E402
 
 SMALL = UNetConfig(in_channels=2, out_channels=2, channels=32, n_res_blocks=1, attention_levels=(1,),
-                   channel_multipliers=(1, 2), n_heads=2, tf_layers=1, d_cond=16)
+                   channel_multipliers=(1, 2), n_heads=2, tf_layers=1, d_cond=32)
 CHD8 = UNetConfig(d_cond=512)
 TXT = UNetConfig(d_cond=1024)
 LIN = (0.00085, 0.012)
@@ -138,8 +138,8 @@ def main():
     rng = np.random.Generator(np.random.PCG64(11))
     x = torch.from_numpy(rng.standard_normal((3, 2, 32, 32)).astype(np.float32))
     tt = torch.tensor([0, 417, 999])
-    c1 = torch.from_numpy(rng.standard_normal((3, 1, 16)).astype(np.float32))
-    c4 = torch.from_numpy(rng.standard_normal((3, 4, 16)).astype(np.float32))
+    c1 = torch.from_numpy(rng.standard_normal((3, 1, 32)).astype(np.float32))
+    c4 = torch.from_numpy(rng.standard_normal((3, 4, 32)).astype(np.float32))
     net = ldm_s.eps_model
     trace = {}
     hooks = []
@@ -200,8 +200,8 @@ def main():
     sdf2 = mod.SDFSampler(ldm_s)
     toy = lambda x, t, c: x * c.mean(dim=(1, 2))[:, None, None, None] + t[:, None, None, None].float() * 1e-3
     sdf2.model = toy
-    cc = torch.from_numpy(rng.standard_normal((2, 1, 16)).astype(np.float32))
-    uc = -torch.ones(2, 1, 16)
+    cc = torch.from_numpy(rng.standard_normal((2, 1, 32)).astype(np.float32))
+    uc = -torch.ones(2, 1, 32)
     tcfg = torch.tensor([7, 7])
     g6["cfg_c"] = cc.numpy()
     for s in (0.0, 1.0, 5.0):
@@ -213,8 +213,8 @@ def main():
     rng = np.random.Generator(np.random.PCG64(21))
     B = 2
     shape = (B, 2, 16, 16)
-    cond = torch.from_numpy(rng.standard_normal((B, 1, 16)).astype(np.float32))
-    uc = -torch.ones(B, 1, 16)
+    cond = torch.from_numpy(rng.standard_normal((B, 1, 32)).astype(np.float32))
+    uc = -torch.ones(B, 1, 32)
     start = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
     orig = torch.from_numpy((rng.random(shape) < 0.1).astype(np.float32))
     mask = torch.zeros(shape)
