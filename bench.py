@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py - denoising steps/sec on MI355X for BASELINE.json config 2
+(sdf_chd8bar conditional generation, batch 16 per GPU, DDPM sampler).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one iteration of SDFSampler.paint's loop on a batch of 16 piano rolls: the
+conditional UNet evaluation (uncond_scale = 1 -> one eval per sample), two on-device noise draws
+and the fused DDPM/RePaint update - exactly what `inference_sdf` executes per reverse step.
+Inputs (x_T, chord condition from the HIP chord encoder, weights) are resident in HBM before
+the timed region.  Rank 0 prints ONE JSON line; `value` is the whole-job aggregate (sum over GPUs,
+weak scaling: every GPU denoises its own batch of 16).
+
+Extra objects (see DESIGN.md "Measurement"):
+  roofline     - the dominant kernel family (conv_mfma 3x3, fp32 MFMA): algorithmic FLOPs of its
+                 launches / their summed duration, measured with hipEvents around every launch
+                 on the launch stream in a separate profiled pass of the same workload.
+  cpu_baseline - the CPU oracle (same ATen ops as the reference) timed on this host's cores on a
+                 bounded sample (2 steps at batch 16), rank 0 and N == 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from polyffusion_amd import _lib, dist as pfdist, synth  # noqa: E402
+from polyffusion_amd.arch import UNetConfig  # noqa: E402
+from polyffusion_amd.inference_sdf import build_encoders, build_ldm, build_unet  # noqa: E402
+from polyffusion_amd.model_sdf import Polyffusion_SDF  # noqa: E402
+from polyffusion_amd.params import preset  # noqa: E402
+from polyffusion_amd.sampler import SDFSampler  # noqa: E402
+from polyffusion_amd.weights import synth_chord_encoder_state, synth_unet_state  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+F_MIN_PER_SAMPLE_EVAL = 89.338e9  # algorithmic FLOPs per UNet sample-eval, n_cond == 1 dead math removed
+BATCH = 16
+KIND_NAMES = ["conv3x3_mfma", "gemm_mfma", "attention", "gn_stats", "ln_stats", "small"]
+
+
+def build_model(params, rank, world):
+    """rank 0 generates + packs the weights; everyone else receives the packed blobs (RCCL broadcast)."""
+    unet = build_unet(params)
+    chord_enc, _ = build_encoders(params)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if rank == 0:
+        ublob = unet.pack_state_dict(synth_unet_state(UNetConfig.from_params(params), 0)).to(dev)
+        cblob = chord_enc.pack_state_dict(synth_chord_encoder_state(0)).to(dev)
+    else:
+        ublob = torch.empty(unet.weight_bytes() // 4, dtype=torch.float32, device=dev)
+        cblob = torch.empty(_lib.load().pf_encoder_weight_bytes(chord_enc._h) // 4, dtype=torch.float32, device=dev)
+    t0 = time.perf_counter()
+    pfdist.broadcast_blob(ublob, 0)
+    pfdist.broadcast_blob(cblob, 0)
+    torch.cuda.synchronize()
+    bcast_s = time.perf_counter() - t0
+    unet.bind_packed(ublob)
+    chord_enc.bind_packed(cblob)
+    model = Polyffusion_SDF(build_ldm(params, unet), params.cond_type, params.cond_mode, chord_enc=chord_enc)
+    return model, bcast_s
+
+
+def cpu_baseline(params, n_steps=2):
+    """Oracle (reference ATen ops on CPU) on a bounded sample: n_steps DDPM steps at batch 16."""
+    from oracle import sampler_ref, unet_ref
+    cfg = UNetConfig.from_params(params)
+    w = unet_ref.to_torch(synth_unet_state(cfg, 0))
+    threads = torch.get_num_threads()
+    x = torch.from_numpy(synth.gaussian((BATCH, 2, 128, 128), 1234))
+    c = torch.from_numpy(synth.gaussian((BATCH, 1, cfg.d_cond), 77))
+    rng = np.random.Generator(np.random.PCG64(5))
+    noise = lambda shape: torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+    model = lambda x_, t_, c_: unet_ref.unet_forward(w, cfg, x_, t_, c_)
+    s = sampler_ref.SDFSamplerRef(model, 1000, params.linear_start, params.linear_end, noise_fn=noise)
+    z = torch.zeros_like(x)
+    with torch.no_grad():
+        model(x[:1], torch.tensor([999]), c[:1])  # warm-up (thread pool, oneDNN primitives)
+        t0 = time.perf_counter()
+        for step in range(999, 999 - n_steps, -1):
+            x_kn = s.q_sample(z, step, noise(x.shape))
+            x_un, _, _ = s.p_sample(x, c, step)
+            x = x_kn * z + x_un * (1 - z)
+        dt = time.perf_counter() - t0
+    return {"value": n_steps / dt, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n_steps} DDPM steps at batch {BATCH} (sdf_chd8bar) through oracle/unet_ref.py + sampler_ref.py, "
+                      f"{threads} torch threads of {os.cpu_count()} host CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--profile-steps", type=int, default=2, help="profiled steps for the roofline object (0 disables)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = pfdist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if args.gpus != 1 or world != 1:
+            sys.exit(2)
+    _lib.require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    params = preset("sdf_chd8bar")
+    model, bcast_s = build_model(params, rank, world)
+    unet = model.ldm.eps_model
+
+    # per-rank batch of 16: global sample indices [rank*16, rank*16+16) -> noise streams independent of N
+    lo = rank * BATCH
+    chords = torch.from_numpy(synth.chords(BATCH * world, seed=4242)[lo:lo + BATCH]).to(dev)
+    cond = model._encode_chord(chords)  # [16,1,512] through the HIP chord encoder
+    sampler = SDFSampler(model.ldm, seed=1234, sample_offset=lo)
+    shape = (BATCH, params.out_channels, params.img_h, params.img_w)
+    zeros = torch.zeros(shape, device=dev)
+    x = sampler.q_sample(zeros, params.n_steps - 1, sampler.randn(shape, dev))  # what Experiments.predict feeds paint()
+    n = x.numel()
+    lib = _lib.load()
+    import ctypes as C
+
+    def step_fn(x_t, step):
+        coef = sampler._coef(step)
+        noise_q = sampler.randn(shape, dev) if step > 0 else None
+        e_t = sampler._eps(x_t, cond, step, 1.0, None, None)
+        noise_p = sampler.randn(shape, dev) if step > 0 else None
+        out = torch.empty_like(x_t)
+        _lib.check(lib.pf_ddpm_step(x_t.data_ptr(), e_t.data_ptr(), _lib.ptr(noise_p), _lib.ptr(noise_q), zeros.data_ptr(),
+                                    zeros.data_ptr(), C.byref(coef), out.data_ptr(), n, _lib.current_stream()))
+        return out
+
+    t_step = params.n_steps - 1
+    for _ in range(args.warmup):
+        x = step_fn(x, t_step); t_step = max(t_step - 1, 1)
+    torch.cuda.synchronize(); pfdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = step_fn(x, t_step); t_step = max(t_step - 1, 1)
+    torch.cuda.synchronize(); pfdist.barrier()
+    elapsed = pfdist.max_over_ranks(time.perf_counter() - t0)
+    assert torch.isfinite(x).all(), "non-finite sample"
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed
+    out = {
+        "metric": "denoising steps/sec (8-bar prmat2c, batch 16)", "value": round(value, 4), "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "sdf_chd8bar cond generation, batch 16 per GPU, 1000-step DDPM sampler loop body "
+                               "(BASELINE.json configs[1]); weights: deterministic synthetic, 41.08M params",
+                   "global_batch": BATCH * world, "unet_evals_per_step": BATCH * world, "parallelism": f"batch-shard x{world}",
+                   "weight_broadcast_s": round(bcast_s, 4), "launches_per_step": unet.n_launches(BATCH) + 3},
+        "path_tflops": round(F_MIN_PER_SAMPLE_EVAL * BATCH * world * args.steps / elapsed / 1e12, 3),
+        "path_frac_of_f32_mfma_peak": round(F_MIN_PER_SAMPLE_EVAL * BATCH * args.steps / elapsed / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+    }
+
+    if rank == 0 and args.profile_steps > 0:
+        unet.set_profiling(True)
+        agg = {}
+        for _ in range(args.profile_steps):
+            x = step_fn(x, t_step)
+            torch.cuda.synchronize()
+            for kind, ms, fl in unet.read_profile():
+                a = agg.setdefault(kind, [0, 0.0, 0.0])
+                a[0] += 1; a[1] += ms; a[2] += fl
+        unet.set_profiling(False)
+        k = agg.get(0)
+        if k:
+            ach = k[2] / (k[1] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                               "kernel": "conv_mfma_kernel<3x3> (fp32 MFMA, fused GN+SiLU prologue)",
+                               "launches_per_step": k[0] // args.profile_steps,
+                               "avg_launch_ms": round(k[1] / k[0], 4),
+                               "flops_per_step": k[2] / args.profile_steps}
+        out["kernel_ms_per_step"] = {KIND_NAMES[kind]: round(v[1] / args.profile_steps, 4) for kind, v in sorted(agg.items())}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(params)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    pfdist.barrier()
+
+
+if __name__ == "__main__":
+    main()
