@@ -50,8 +50,9 @@ int launch_conv_out(const float* x_nhwc, const float* sc, const float* sh, const
 int launch_time_embed(const int64_t* t, const float* w0, const float* b0, const float* w2, const float* b2,
                       float* out_silu, int batch, int channels, int d_t, hipStream_t stream);
 // y[b][n] = sum_k W[n][k] * x[b][k] + bias[n]   (row-major W [N][K]; one wave per output)
+// grouped form: output n reads x + (n / n_per_group) * x_group_stride (block-diagonal W); n_per_group <= 0 disables
 int launch_matvec(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int batch, int n, int k,
-                  hipStream_t stream);
+                  hipStream_t stream, int n_per_group = 0, int x_group_stride = 0);
 
 // sampler elementwise kernels
 int launch_cfg_combine(const float* eps2, float scale, float* eps, size_t n, hipStream_t s);

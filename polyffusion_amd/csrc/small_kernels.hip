@@ -182,9 +182,9 @@ int launch_time_embed(const int64_t* t, const float* w0, const float* b0, const 
 
 // ------------------------------------------------------------------ batched mat-vec: y[b][n] = W[n][:] . x[b][:] + bias[n]
 // one wave per output n (8 outputs per wave), 8 batch rows per block so each weight row is read once per 8 samples.
-__global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ x0, int ldx, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y, int ldy, int B, int N,
-                                                     int K) {
+                                                     int K, int n_per_group, int x_group_stride) {
   constexpr int RB = 8, OPW = 8;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b0 = blockIdx.y * RB;
@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ x
     const int n = (blockIdx.x * 4 + wave) * OPW + o;
     if (n >= N) return;
     const float* wr = w + (size_t)n * K;
+    const float* x = x0 + (size_t)(n / n_per_group) * x_group_stride;  // block-diagonal (grouped) form
     float acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = 0.f;
@@ -225,9 +226,11 @@ __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ x
 }
 
 int launch_matvec(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int batch, int n, int k,
-                  hipStream_t stream) {
+                  hipStream_t stream, int n_per_group, int x_group_stride) {
   PF_REQUIRE(x && w && y && batch > 0 && n > 0 && k > 0, "matvec: bad arguments");
-  hipLaunchKernelGGL(matvec_kernel, dim3(cdiv(n, 32), cdiv(batch, 8)), dim3(256), 0, stream, x, ldx, w, bias, y, ldy, batch, n, k);
+  if (n_per_group <= 0) { n_per_group = n; x_group_stride = 0; }
+  hipLaunchKernelGGL(matvec_kernel, dim3(cdiv(n, 32), cdiv(batch, 8)), dim3(256), 0, stream, x, ldx, w, bias, y, ldy, batch, n, k,
+                     n_per_group, x_group_stride);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }

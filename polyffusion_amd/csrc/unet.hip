@@ -39,7 +39,7 @@ struct Layer {
   int emb_off;                                                        // column offset into the all-ResBlock time-bias matrix
   // spatial transformer
   size_t norm_g, norm_b, pin_w, pin_b, pout_w, pout_b;
-  struct TB { size_t n1g, n1b, n2g, n2b, n3g, n3b, qkv, o1w, o1b, q2, kv2, o2w, o2b, v2raw, o2raw, ff1w, ff1b, ff2w, ff2b; };
+  struct TB { int cross_off; size_t n1g, n1b, n2g, n2b, n3g, n3b, qkv, o1w, o1b, q2, kv2, o2w, o2b, v2raw, o2raw, ff1w, ff1b, ff2w, ff2b; };
   std::vector<TB> tbs;
   int st_index;
 };
@@ -59,6 +59,13 @@ struct pf_unet {
   std::map<std::string, int> index;
   size_t blob_floats = 0;
   size_t te_w0, te_b0, te_w2, te_b2, emb_w, emb_b, out_g, out_b, out_w, out_bias, in_w, in_b;
+  // n_cond == 1 cross-attention collapse: to_v / to_out / bias of ALL transformer blocks, contiguous
+  size_t cross_v = 0, cross_o = 0, cross_b = 0;
+  int cross_total = 0;          // sum of C over transformer blocks
+  bool cross_uniform = true;    // every block has the same C -> two grouped launches
+  int cross_c = 0;
+  int cross_cursor = 0;
+  size_t cross_o_cursor = 0;
   const float* wdev = nullptr;
   // profiling
   bool profiling = false;
@@ -138,13 +145,17 @@ static void build_st(pf_unet* u, const std::string& p, Layer& L) {
     {
       ParamSpec& ps = u->add(tb + ".attn2.to_v.weight", {C, dc});
       ps.dests.push_back(Dest{D_GEMM, t.kv2, 1, dc, C, (2 * C + 63) / 64 * 64, C});
-      t.v2raw = u->alloc((size_t)C * dc);
+      t.cross_off = u->cross_cursor;
+      u->cross_cursor += C;
+      t.v2raw = u->cross_v + (size_t)t.cross_off * dc;
       u->params[u->index[tb + ".attn2.to_v.weight"]].dests.push_back(Dest{D_RAW, t.v2raw, 1, 0, 0, 0, 0});
     }
     t.o2w = u->add_gemm(tb + ".attn2.to_out.0.weight", C, C, 1);
-    t.o2raw = u->alloc((size_t)C * C);
+    t.o2raw = u->cross_o + u->cross_o_cursor;
+    u->cross_o_cursor += (size_t)C * C;
     u->params.back().dests.push_back(Dest{D_RAW, t.o2raw, 1, 0, 0, 0, 0});
     t.o2b = u->add_raw(tb + ".attn2.to_out.0.bias", {C});
+    u->params.back().dests.push_back(Dest{D_RAW, u->cross_b + (size_t)t.cross_off, 1, 0, 0, 0, 0});
     t.n1g = u->add_raw(tb + ".norm1.weight", {C}); t.n1b = u->add_raw(tb + ".norm1.bias", {C});
     t.n2g = u->add_raw(tb + ".norm2.weight", {C}); t.n2b = u->add_raw(tb + ".norm2.bias", {C});
     t.n3g = u->add_raw(tb + ".norm3.weight", {C}); t.n3b = u->add_raw(tb + ".norm3.bias", {C});
@@ -242,6 +253,26 @@ static int build(pf_unet* u) {
     }
   }
   u->final_ch = ch;
+
+  // n_cond == 1 cross-attention collapse: one contiguous region for all blocks' to_v / to_out / bias
+  {
+    size_t o_floats = 0;
+    auto visit = [&](const Layer& L) {
+      if (L.kind != 2) return;
+      for (int i = 0; i < c.tf_layers; ++i) {
+        if (u->cross_c == 0) u->cross_c = L.cin;
+        if (L.cin != u->cross_c) u->cross_uniform = false;
+        u->cross_total += L.cin;
+        o_floats += (size_t)L.cin * L.cin;
+      }
+    };
+    for (auto& b : u->in_blocks) for (auto& L : b.layers) visit(L);
+    for (auto& L : u->mid.layers) visit(L);
+    for (auto& b : u->out_blocks) for (auto& L : b.layers) visit(L);
+    u->cross_v = u->alloc((size_t)u->cross_total * c.d_cond);
+    u->cross_o = u->alloc(o_floats);
+    u->cross_b = u->alloc((size_t)u->cross_total);
+  }
 
   // parameter table in the reference key order
   for (size_t bi = 0; bi < u->in_blocks.size(); ++bi)
@@ -446,8 +477,8 @@ static float* run_st(Ctx& c, const Layer& L, const float* x, int H, int W_, cons
       pf_conv_args a = conv_base(att, C, nullptr, 0, B, 1, hw, 1, c.w(t.o1w), C, t1);
       a.bias = c.w(t.o1b); a.res = t0; a.ld_res = C;
       if (c.n_cond == 1) {  // x = attn2(LN2(x), c) + x collapses to a per-sample bias (softmax over one key == 1)
-        a.sbias = c.dry ? nullptr : cross_all + ((size_t)(L.st_index * c.u->cfg.tf_layers + i) * B) * c.cross_cmax;
-        a.ld_sbias = C;
+        a.sbias = c.dry ? nullptr : cross_all + t.cross_off;
+        a.ld_sbias = c.u->cross_total;
       }
       c.conv(a, PF_K_GEMM);
     }
@@ -508,27 +539,31 @@ static int run(pf_unet* u, Ctx& c, const float* x, const int64_t* t, const float
   c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_time_embed(t, c.w(u->te_w0), c.w(u->te_b0), c.w(u->te_w2), c.w(u->te_b2), tsilu, B, cfg.channels, u->d_t, c.s)); c.prof_end();
   c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_matvec(tsilu, u->d_t, c.w(u->emb_w), c.w(u->emb_b), tb_all, u->sum_emb, B, u->sum_emb, u->d_t, c.s)); c.prof_end();
   // n_cond == 1: per-sample cross-attention bias to_out(to_v(c)) for every transformer block
-  float* cross_all = nullptr;
-  if (c.n_cond == 1) {
-    const int ntb = u->n_st * cfg.tf_layers;
-    int cmax = 0;
-    auto each_st = [&](auto&& fn) {
-      for (auto& b : u->in_blocks) for (auto& L : b.layers) if (L.kind == 2) fn(L);
-      for (auto& L : u->mid.layers) if (L.kind == 2) fn(L);
-      for (auto& b : u->out_blocks) for (auto& L : b.layers) if (L.kind == 2) fn(L);
-    };
-    each_st([&](const Layer& L) { cmax = std::max(cmax, L.cin); });
-    c.cross_cmax = cmax;
-    cross_all = c.palloc((size_t)ntb * B * cmax);
-    float* vtmp = c.palloc((size_t)B * cmax);
-    each_st([&](const Layer& L) {
-      const int C = L.cin;
-      for (size_t i = 0; i < L.tbs.size(); ++i) {
-        float* dst = c.dry ? nullptr : cross_all + ((size_t)(L.st_index * cfg.tf_layers + i) * B) * cmax;
-        c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_matvec(cond, cfg.d_cond, c.w(L.tbs[i].v2raw), nullptr, vtmp, C, B, C, cfg.d_cond, c.s)); c.prof_end();
-        c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_matvec(vtmp, C, c.w(L.tbs[i].o2raw), c.w(L.tbs[i].o2b), dst, C, B, C, C, c.s)); c.prof_end();
-      }
-    });
+  float* cross_all = nullptr;  // [B][cross_total]: to_out(to_v(c)) + bias of every transformer block
+  if (c.n_cond == 1 && u->cross_total > 0) {
+    const int T = u->cross_total;
+    cross_all = c.palloc((size_t)B * T);
+    float* vtmp = c.palloc((size_t)B * T);
+    c.prof_begin(PF_K_SMALL, 0);
+    if (!c.dry) small_launch(c, launch_matvec(cond, cfg.d_cond, c.w(u->cross_v), nullptr, vtmp, T, B, T, cfg.d_cond, c.s));
+    c.prof_end();
+    if (u->cross_uniform) {
+      c.prof_begin(PF_K_SMALL, 0);
+      if (!c.dry) small_launch(c, launch_matvec(vtmp, T, c.w(u->cross_o), c.w(u->cross_b), cross_all, T, B, T, u->cross_c, c.s, u->cross_c, u->cross_c));
+      c.prof_end();
+    } else {
+      auto each_tb = [&](const Layer& L) {
+        if (L.kind != 2) return;
+        for (const Layer::TB& t : L.tbs) {
+          c.prof_begin(PF_K_SMALL, 0);
+          if (!c.dry) small_launch(c, launch_matvec(vtmp + t.cross_off, T, c.w(t.o2raw), c.w(t.o2b), cross_all + t.cross_off, T, B, L.cin, L.cin, c.s));
+          c.prof_end();
+        }
+      };
+      for (auto& b : u->in_blocks) for (auto& L : b.layers) each_tb(L);
+      for (auto& L : u->mid.layers) each_tb(L);
+      for (auto& b : u->out_blocks) for (auto& L : b.layers) each_tb(L);
+    }
   }
 
   std::vector<const float*> skips;
