@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=2, help="profiled steps for the roofline object (0 disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
+                    help="arithmetic of the dense contractions: exact fp32 MFMA, or the error-compensated bf16x3 split")
+    ap.add_argument("--dump-launches", action="store_true", help="print one line per kernel launch of a profiled step (stderr)")
     args = ap.parse_args()
 
     rank, world, local = pfdist.init_from_env()
@@ -115,6 +118,7 @@ def main():
     params = preset("sdf_chd8bar")
     model, bcast_s = build_model(params, rank, world)
     unet = model.ldm.eps_model
+    unet.set_precision(args.precision)
 
     # per-rank batch of 16: global sample indices [rank*16, rank*16+16) -> noise streams independent of N
     lo = rank * BATCH
@@ -169,7 +173,9 @@ def main():
         for _ in range(args.profile_steps):
             x = step_fn(x, t_step)
             torch.cuda.synchronize()
-            for kind, ms, fl in unet.read_profile():
+            for i, (kind, ms, fl) in enumerate(unet.read_profile()):
+                if args.dump_launches and _ == 0:
+                    print(f"launch {i:3d} {KIND_NAMES[kind]:14s} {ms * 1e3:8.1f} us {fl / 1e9:8.2f} GF {fl / max(ms, 1e-9) / 1e9:7.1f} TF/s", file=sys.stderr)
                 a = agg.setdefault(kind, [0, 0.0, 0.0])
                 a[0] += 1; a[1] += ms; a[2] += fl
         unet.set_profiling(False)

@@ -127,10 +127,21 @@ size_t pf_encoder_workspace_bytes(const pf_encoder* e, int batch);
 int pf_encoder_forward(pf_encoder* e, const float* x, int batch, int n_step, float* mu,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Arithmetic of the dense contractions (convs / linears):
+ *   PF_PREC_F32    - v_mfma_f32_32x32x2_f32, exact fp32 FMA chains (157 TFLOP/s pipe);
+ *   PF_PREC_BF16X3 - error-compensated split on the bf16 pipe: a.w ~= a_hi.w_hi + a_hi.w_lo + a_lo.w_hi with fp32
+ *                    accumulation (~1e-5 relative per product, three v_mfma_f32_32x32x16_bf16 instead of eight fp32 MFMAs).
+ * Both packings of every weight live in the blob; the mode can be switched between calls. */
+enum { PF_PREC_F32 = 0, PF_PREC_BF16X3 = 1 };
+int pf_unet_set_precision(pf_unet* u, int precision);
+int pf_unet_get_precision(const pf_unet* u);
+
 /* ---- per-op entry points (unit-testable kernels; same kernels the plan launches) ---------- */
 /* Host helper: torch weight [N, K, kh, kw] (kh=kw=1 or 3) -> packed [kh*kw][K/4][Npad][4], Npad = roundup(N,64). */
 size_t pf_packed_gemm_weight_floats(int n, int k, int taps);
 int pf_pack_gemm_weight(const float* w, int n, int k, int taps, float* dst);
+/* same bytes, bf16x3 packing [kh*kw][K/8][hi|lo][Npad][8] (bf16); needs k % 8 == 0 */
+int pf_pack_gemm_weight_bf16x3(const float* w, int n, int k, int taps, void* dst);
 
 /* GroupNorm statistics on NHWC (optionally the channel-concat of two tensors) -> per-(b,c)
  * scale/shift so that y = x*scale + shift equals GroupNorm(x) (unet.py:321-336; eps 1e-5 / 1e-6). */
@@ -153,6 +164,7 @@ typedef struct pf_conv_args {
   const float* bias; const float* sbias; int32_t ld_sbias; const float* res; int32_t ld_res;
   int32_t geglu;
   float* out; int32_t ld_out;
+  int32_t precision;                                         /* PF_PREC_F32 (w = fp32 packing) | PF_PREC_BF16X3 (w = bf16x3 packing) */
 } pf_conv_args;
 int pf_conv2d(const pf_conv_args* a, void* stream);
 

@@ -45,6 +45,7 @@ class ConvArgs(C.Structure):
         ("bias", C.c_void_p), ("sbias", C.c_void_p), ("ld_sbias", C.c_int32), ("res", C.c_void_p), ("ld_res", C.c_int32),
         ("geglu", C.c_int32),
         ("out", C.c_void_p), ("ld_out", C.c_int32),
+        ("precision", C.c_int32),
     ]
 
 
@@ -81,6 +82,9 @@ SIGNATURES = {
     "pf_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_packed_gemm_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "pf_pack_gemm_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pf_pack_gemm_weight_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pf_unet_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "pf_unet_get_precision": (C.c_int, [C.c_void_p]),
     "pf_gn_scale_shift": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_ln_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),

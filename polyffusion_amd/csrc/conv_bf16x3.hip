@@ -1,0 +1,380 @@
+// conv_bf16x3.hip - the same implicit-GEMM convolution / linear as conv_mfma.hip, computed on the
+// bf16 matrix pipe with an error-compensated split ("bf16x3"):
+//
+//      a = a_hi + a_lo,  w = w_hi + w_lo   (hi = bf16_rne(x), lo = bf16_rne(x - hi))
+//      a.w ~= a_hi.w_hi + a_hi.w_lo + a_lo.w_hi          (fp32 accumulate inside the MFMA)
+//
+// Every bf16 x bf16 product is exact in fp32, the dropped a_lo.w_lo term and the two representation
+// errors are each <= 2^-18 relative, so a product carries ~1e-5 relative error (vs 2^-9 for plain
+// bf16, which misses the 1e-3 parity bar by 20x - SURVEY.md 0) while running on
+// v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense) instead of the 157 TFLOP/s fp32 MFMA: 3 bf16 MFMAs
+// replace 8 fp32 MFMAs of twice the latency, a 5.3x higher matrix-pipe ceiling.
+//
+// Structure = conv_mfma.hip (halo tile in LDS, weights per (chunk, tap), fused GN+SiLU / LayerNorm
+// prologue and bias / residual / GeGLU epilogue, XCD-aware block remap).  Differences:
+//   * activations are split into hi/lo bf16 planes when the tile is staged (after the prologue
+//     transform, 3.5 VALU ops per element, once per element per block);
+//   * weights are pre-split on the host and packed [tap][K/8][plane][Npad][8] so that a lane's eight
+//     consecutive-k B operands are one 16-byte LDS read per plane;
+//   * BK = 32; the 3x3 halo image is single-buffered (it changes every 9 taps; its global loads are
+//     issued three taps ahead), weight tiles are double-buffered; 1x1 mode double-buffers both.
+#include "pf_internal.h"
+
+namespace pf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvP3 {
+  const float* x0; const float* x1; int c0, c1;
+  int B, Hin, Win, Hout, Wout;
+  const __bf16* w; int N, Npad;
+  const float* sc; const float* sh; const float* mean; const float* rstd;
+  const float* bias; const float* sbias; int ld_sbias; const float* res; int ld_res;
+  int geglu;
+  float* out; int ld_out;
+  int tiles_x, tiles_y, nt;
+};
+
+__device__ __forceinline__ float silu3_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float gelu3_erf_f(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)); }
+
+template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO>
+__global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
+  constexpr int BK = 32;
+  constexpr int BM = TH * TW;
+  constexpr int THIN = (TH - 1) * STRIDE + KS;
+  constexpr int TWIN = (TW - 1) * STRIDE + KS;
+  constexpr int NPIX = THIN * TWIN;
+  constexpr int PITCH = BK + 8;            // bf16 elements per pixel row (80 B: conflict-free b128 for consecutive pixels)
+  constexpr int KQ = BK / 4;               // float4 per pixel per chunk (global side)
+  constexpr int TOTA = NPIX * KQ;
+  constexpr int NA = (TOTA + 255) / 256;
+  constexpr int PSTEP = 256 / KQ;          // 32 pixels between a thread's successive float4
+  constexpr int TOTW = 8 * BN;             // 16-byte units per W tile (2 planes x 4 k8 x BN)
+  constexpr int NW = TOTW / 256;
+  constexpr int TAPS = KS * KS;
+  constexpr int NABUF = (KS == 1) ? 2 : 1;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int FM = WM / 32, FN = WN / 32;
+  constexpr int PAD = (KS == 3) ? 1 : 0;
+  constexpr int APLANE = NABUF * NPIX * PITCH;  // bf16 elements per A plane
+  static_assert(TOTW % 256 == 0 && FM >= 1 && FN >= 1, "bad tile");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* sAh = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* sAl = sAh + APLANE;
+  __bf16* sW = sAl + APLANE;               // [2 bufs][2 planes][4][BN][8]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = gridDim.x;
+  int lid;
+  {
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int nti = lid % p.nt;
+  int mt = lid / p.nt;
+  const int tx = mt % p.tiles_x; mt /= p.tiles_x;
+  const int ty = mt % p.tiles_y;
+  const int b = mt / p.tiles_y;
+  const int n0 = nti * BN;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
+  const int Hlog = UPS ? 2 * p.Hin : p.Hin, Wlog = UPS ? 2 * p.Win : p.Win;
+  const int cin = p.c0 + p.c1;
+  const int K8 = cin / 8;
+
+  const int c4 = tid % KQ;
+  int poff[NA];
+  float pmu[NA], prs[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int pix = tid / KQ + i * PSTEP;
+    poff[i] = -1; pmu[i] = 0.f; prs[i] = 0.f;
+    if (pix < NPIX) {
+      const int hy = pix / TWIN, hx = pix % TWIN;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      if (iy >= 0 && iy < Hlog && ix >= 0 && ix < Wlog) {
+        const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
+        poff[i] = (b * p.Hin + sy) * p.Win + sx;
+        if (PRO == 3) { pmu[i] = p.mean[poff[i]]; prs[i] = p.rstd[poff[i]]; }
+      }
+    }
+  }
+
+  f32x4 ra[NA], vsc, vsh;
+  u32x4 rw[NW];
+  vsc = f32x4{1.f, 1.f, 1.f, 1.f}; vsh = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto loadA = [&](int chunk) {
+    const int cg = chunk * BK;
+    const float* src; int cs, co;
+    if (cg < p.c0) { src = p.x0; cs = p.c0; co = cg; } else { src = p.x1; cs = p.c1; co = cg - p.c0; }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      if (poff[i] >= 0) ra[i] = *reinterpret_cast<const f32x4*>(src + (size_t)poff[i] * cs + co + c4 * 4);
+      else ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (PRO == 1 || PRO == 2) {
+      vsc = *reinterpret_cast<const f32x4*>(p.sc + (size_t)b * cin + cg + c4 * 4);
+      vsh = *reinterpret_cast<const f32x4*>(p.sh + (size_t)b * cin + cg + c4 * 4);
+    } else if (PRO == 3) {
+      vsc = *reinterpret_cast<const f32x4*>(p.sc + cg + c4 * 4);
+      vsh = *reinterpret_cast<const f32x4*>(p.sh + cg + c4 * 4);
+    }
+  };
+  auto storeA = [&](int buf) {
+    const int base = buf * (NPIX * PITCH) + (tid / KQ) * PITCH + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      if (tid / KQ + i * PSTEP < NPIX) {
+        f32x4 v = ra[i];
+        if (PRO != 0 && poff[i] >= 0) {
+          if (PRO == 3) {
+            v = (v - pmu[i]) * prs[i] * vsc + vsh;
+          } else {
+            v = v * vsc + vsh;
+            if (PRO == 1) { v[0] = silu3_f(v[0]); v[1] = silu3_f(v[1]); v[2] = silu3_f(v[2]); v[3] = silu3_f(v[3]); }
+          }
+        }
+        const bf16x4 h = __builtin_convertvector(v, bf16x4);
+        const f32x4 hf = __builtin_convertvector(h, f32x4);
+        const bf16x4 l = __builtin_convertvector(v - hf, bf16x4);
+        *reinterpret_cast<bf16x4*>(sAh + base + i * PSTEP * PITCH) = h;
+        *reinterpret_cast<bf16x4*>(sAl + base + i * PSTEP * PITCH) = l;
+      }
+    }
+  };
+  auto loadW = [&](int chunk, int tap) {
+    const size_t k8b = (size_t)tap * K8 + (size_t)chunk * 4;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int u = tid + j * 256;
+      const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
+      rw[j] = *reinterpret_cast<const u32x4*>(p.w + ((((k8b + k8l) * 2 + plane) * p.Npad) + n0 + n) * 8);
+    }
+  };
+  auto storeW = [&](int buf) {
+    __bf16* dst = sW + buf * (TOTW * 8);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int u = tid + j * 256;
+      const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
+      *reinterpret_cast<u32x4*>(dst + ((plane * 4 + k8l) * BN + n) * 8) = rw[j];
+    }
+  };
+
+  int hbase[FM];
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm) {
+    const int pp = wm * WM + fm * 32 + (lane & 31);
+    const int py = pp / TW, px = pp % TW;
+    hbase[fm] = ((py * STRIDE) * TWIN + px * STRIDE) * PITCH + 8 * (lane >> 5);
+  }
+  const int wbase = ((lane >> 5) * BN + wn * WN + (lane & 31)) * 8;
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[fm][fn][r] = 0.f;
+
+  const int nchunk = cin / BK;
+
+  loadA(0); loadW(0, 0);
+  storeA(0); storeW(0);
+  __syncthreads();
+
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const int nchunk1 = min(chunk + 1, nchunk - 1);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int wpar = (chunk * TAPS + tap) & 1;
+      if (tap + 1 < TAPS) loadW(chunk, tap + 1); else loadW(nchunk1, 0);
+      if (tap == (TAPS >= 3 ? TAPS - 3 : 0)) loadA(nchunk1);
+
+      const int abuf = (NABUF == 2) ? (chunk & 1) : 0;
+      const int aoff = abuf * (NPIX * PITCH) + ((tap / KS) * TWIN + (tap % KS)) * PITCH;
+      const __bf16* cW = sW + wpar * (TOTW * 8) + wbase;
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+          ah[fm] = *reinterpret_cast<const bf16x8*>(sAh + aoff + hbase[fm] + s * 16);
+          al[fm] = *reinterpret_cast<const bf16x8*>(sAl + aoff + hbase[fm] + s * 16);
+        }
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+          bh[fn] = *reinterpret_cast<const bf16x8*>(cW + ((2 * s) * BN + fn * 32) * 8);
+          bl[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 + 2 * s) * BN + fn * 32) * 8);
+        }
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+      }
+
+      storeW(wpar ^ 1);
+      if (NABUF == 2) {
+        storeA((chunk + 1) & 1);
+        __syncthreads();
+      } else {
+        __syncthreads();
+        if (tap == TAPS - 1) {   // every wave has finished reading this chunk's halo: overwrite it
+          storeA(0);
+          __syncthreads();
+        }
+      }
+    }
+  }
+
+  const float* sb = p.sbias ? p.sbias + (size_t)b * p.ld_sbias : nullptr;
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int pp = wm * WM + fm * 32 + row;
+      const int oy = oy0 + pp / TW, ox = ox0 + pp % TW;
+      if (oy >= p.Hout || ox >= p.Wout) continue;
+      const size_t m = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+      if (p.geglu) {
+        if (FN == 2) {
+          const int nv = n0 + wn * WN + (lane & 31);
+          const int j = (n0 + wn * WN) / 2 + (lane & 31);
+          if (j < p.N / 2) {
+            float v = acc[fm][0][r], g = acc[fm][FN - 1][r];
+            if (p.bias) { v += p.bias[nv]; g += p.bias[nv + 32]; }
+            p.out[m * p.ld_out + j] = v * gelu3_erf_f(g);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+          const int n = n0 + wn * WN + fn * 32 + (lane & 31);
+          if (n < p.N) {
+            float v = acc[fm][fn][r];
+            if (p.bias) v += p.bias[n];
+            if (sb) v += sb[n];
+            if (p.res) v += p.res[m * p.ld_res + n];
+            p.out[m * p.ld_out + n] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO>
+static int launch3_cfg(ConvP3& p, hipStream_t stream) {
+  constexpr int THIN = (TH - 1) * STRIDE + KS, TWIN = (TW - 1) * STRIDE + KS;
+  constexpr int NABUF = (KS == 1) ? 2 : 1;
+  constexpr size_t lds = (size_t)(2 * NABUF * THIN * TWIN * 40 + 2 * 8 * BN * 8) * 2;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  p.tiles_x = cdiv(p.Wout, TW);
+  p.tiles_y = cdiv(p.Hout, TH);
+  p.nt = cdiv(p.Npad, BN);
+  auto kern = conv_bf3_kernel<KS, STRIDE, UPS, TH, TW, BN, PRO>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const int grid = p.B * p.tiles_y * p.tiles_x * p.nt;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+static int pick_tile3(int m_tiles128, int batch, int npad, bool geglu) {
+  if (geglu) return 0;
+  const int nt128 = cdiv(npad, 128), nt64 = cdiv(npad, 64);
+  if (npad >= 128 && npad % 128 == 0 && batch * m_tiles128 * nt128 >= 512) return 0;
+  if (batch * m_tiles128 * nt64 >= 512) return 1;
+  return 2;
+}
+
+template <int KS, int STRIDE, bool UPS, int PRO>
+static int dispatch_tile3(ConvP3& p, int tile, hipStream_t s) {
+  if constexpr (KS == 1) {
+    if (tile == 0) return launch3_cfg<1, 1, false, 1, 128, 128, PRO>(p, s);
+    if (tile == 1) return launch3_cfg<1, 1, false, 1, 128, 64, PRO>(p, s);
+    return launch3_cfg<1, 1, false, 1, 64, 64, PRO>(p, s);
+  } else if constexpr (STRIDE == 2) {
+    return launch3_cfg<3, 2, false, 4, 16, 64, PRO>(p, s);
+  } else {
+    if (tile == 0) return launch3_cfg<3, 1, UPS, 8, 16, 128, PRO>(p, s);
+    if (tile == 1) return launch3_cfg<3, 1, UPS, 8, 16, 64, PRO>(p, s);
+    return launch3_cfg<3, 1, UPS, 4, 16, 64, PRO>(p, s);
+  }
+}
+
+// same argument validation as launch_conv (done by the caller); w points to the bf16x3 packing
+int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
+  ConvP3 p;
+  p.x0 = a.x0; p.x1 = a.x1; p.c0 = a.c0; p.c1 = a.c1;
+  p.B = a.batch; p.Hin = a.hin; p.Win = a.win;
+  p.Hout = a.hin; p.Wout = a.win;
+  if (a.ups) { p.Hout *= 2; p.Wout *= 2; }
+  if (a.stride == 2) { p.Hout = (p.Hout - 1) / 2 + 1; p.Wout = (p.Wout - 1) / 2 + 1; }
+  p.w = reinterpret_cast<const __bf16*>(a.w); p.N = a.n; p.Npad = (a.n + 63) / 64 * 64;
+  p.sc = a.sc; p.sh = a.sh; p.mean = a.mean; p.rstd = a.rstd;
+  p.bias = a.bias; p.sbias = a.sbias; p.ld_sbias = a.ld_sbias; p.res = a.res; p.ld_res = a.ld_res;
+  p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out;
+  int tile;
+  if (a.ks == 1) tile = pick_tile3(cdiv(p.Wout, 128), p.B * p.Hout, p.Npad, a.geglu != 0);
+  else tile = pick_tile3(cdiv(p.Hout, 8) * cdiv(p.Wout, 16), p.B, p.Npad, false);
+  if (a.ks == 1) {
+    switch (a.prologue) {
+      case 0: return dispatch_tile3<1, 1, false, 0>(p, tile, stream);
+      case 2: return dispatch_tile3<1, 1, false, 2>(p, tile, stream);
+      default: return dispatch_tile3<1, 1, false, 3>(p, tile, stream);
+    }
+  }
+  if (a.stride == 2) return dispatch_tile3<3, 2, false, 0>(p, tile, stream);
+  if (a.ups) return dispatch_tile3<3, 1, true, 0>(p, tile, stream);
+  return dispatch_tile3<3, 1, false, 1>(p, tile, stream);
+}
+
+// host: fp32 torch weight [N][K][taps] -> bf16x3 packing [tap][K/8][plane][Npad][8] at column col(n)
+static inline unsigned short f2bf_rne(float f) {
+  unsigned int u; memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+static inline float bf2f(unsigned short h) { unsigned int u = (unsigned int)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+void pack_gemm_bf3(void* dst_, const float* src, int n_src, int K, int taps, int Npad, int n_off, const int* colmap) {
+  unsigned short* dst = (unsigned short*)dst_;
+  const int K8 = K / 8;
+  for (int n = 0; n < n_src; ++n) {
+    const int col = colmap ? colmap[n] : n_off + n;
+    for (int k = 0; k < K; ++k)
+      for (int t = 0; t < taps; ++t) {
+        const float v = src[((size_t)n * K + k) * taps + t];
+        const unsigned short hi = f2bf_rne(v);
+        const unsigned short lo = f2bf_rne(v - bf2f(hi));
+        const size_t base = ((size_t)t * K8 + k / 8) * 2;
+        dst[((base + 0) * Npad + col) * 8 + (k & 7)] = hi;
+        dst[((base + 1) * Npad + col) * 8 + (k & 7)] = lo;
+      }
+  }
+}
+
+}  // namespace pf

@@ -330,6 +330,9 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
   PF_REQUIRE(!(a.ks == 3 && a.prologue == 0 && !a.ups && a.stride == 1), "conv: plain 3x3 without prologue is not instantiated");
   PF_REQUIRE(!(a.ks == 1 && a.prologue == 1), "conv: 1x1 with SiLU prologue is not instantiated");
 
+  PF_REQUIRE(a.precision == PF_PREC_F32 || a.precision == PF_PREC_BF16X3, "conv: bad precision %d", a.precision);
+  if (a.precision == PF_PREC_BF16X3) return launch_conv_bf3(a, stream);
+
   ConvP p;
   p.x0 = a.x0; p.x1 = a.x1; p.c0 = a.c0; p.c1 = a.c1;
   p.B = a.batch; p.Hin = a.hin; p.Win = a.win;

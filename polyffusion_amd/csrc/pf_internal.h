@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <string>
 #include "../../include/pfhip.h"
 
@@ -30,6 +31,8 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // ---- launchers implemented in the .hip files (all enqueue on `stream`, never sync) ----
 int launch_conv(const pf_conv_args& a, hipStream_t stream);
 double conv_flops(const pf_conv_args& a);
+int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream);  // called by launch_conv after validation
+void pack_gemm_bf3(void* dst, const float* src, int n_src, int K, int taps, int Npad, int n_off, const int* colmap);
 
 int launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                      int batch, int n_heads, int d_head, int lq, int lk, hipStream_t stream);

@@ -68,6 +68,7 @@ struct pf_unet {
   size_t cross_o_cursor = 0;
   const float* wdev = nullptr;
   // profiling
+  int precision = PF_PREC_F32;
   bool profiling = false;
   std::vector<hipEvent_t> ev;
   std::vector<int> pkind;
@@ -91,8 +92,10 @@ struct pf_unet {
     add(key, shape).dests.push_back(Dest{D_RAW, off, 1, 0, 0, 0, 0});
   }
   static size_t gemm_floats(int taps, int K, int N) { return (size_t)taps * K * ((N + 63) / 64 * 64); }
+  // every GEMM weight is stored twice, back to back: fp32 packing, then the bf16x3 packing (same byte count)
+  static size_t gemm_alloc(int taps, int K, int N) { return 2 * gemm_floats(taps, K, N); }
   size_t add_gemm(const std::string& key, int N, int K, int taps) {
-    size_t off = alloc(gemm_floats(taps, K, N));
+    size_t off = alloc(gemm_alloc(taps, K, N));
     std::vector<int64_t> shape = taps == 1 ? std::vector<int64_t>{N, K} : std::vector<int64_t>{N, K, 3, 3};
     add(key, shape).dests.push_back(Dest{D_GEMM, off, taps, K, N, (N + 63) / 64 * 64, 0});
     return off;
@@ -132,7 +135,7 @@ static void build_st(pf_unet* u, const std::string& p, Layer& L) {
     Layer::TB t{};
     const std::string tb = p + ".transformer_blocks." + std::to_string(i);
     // attn1: q,k,v fused into one [C -> 3C] matrix
-    t.qkv = u->alloc(pf_unet::gemm_floats(1, C, 3 * C));
+    t.qkv = u->alloc(pf_unet::gemm_alloc(1, C, 3 * C));
     const char* nm[3] = {".attn1.to_q.weight", ".attn1.to_k.weight", ".attn1.to_v.weight"};
     for (int j = 0; j < 3; ++j)
       u->add(tb + nm[j], {C, C}).dests.push_back(Dest{D_GEMM, t.qkv, 1, C, C, (3 * C + 63) / 64 * 64, j * C});
@@ -140,7 +143,7 @@ static void build_st(pf_unet* u, const std::string& p, Layer& L) {
     t.o1b = u->add_raw(tb + ".attn1.to_out.0.bias", {C});
     // attn2: general (n_cond > 1) form + collapsed (n_cond == 1) raw form of to_v / to_out
     t.q2 = u->add_gemm(tb + ".attn2.to_q.weight", C, C, 1);
-    t.kv2 = u->alloc(pf_unet::gemm_floats(1, dc, 2 * C));
+    t.kv2 = u->alloc(pf_unet::gemm_alloc(1, dc, 2 * C));
     u->add(tb + ".attn2.to_k.weight", {C, dc}).dests.push_back(Dest{D_GEMM, t.kv2, 1, dc, C, (2 * C + 63) / 64 * 64, 0});
     {
       ParamSpec& ps = u->add(tb + ".attn2.to_v.weight", {C, dc});
@@ -159,7 +162,7 @@ static void build_st(pf_unet* u, const std::string& p, Layer& L) {
     t.n1g = u->add_raw(tb + ".norm1.weight", {C}); t.n1b = u->add_raw(tb + ".norm1.bias", {C});
     t.n2g = u->add_raw(tb + ".norm2.weight", {C}); t.n2b = u->add_raw(tb + ".norm2.bias", {C});
     t.n3g = u->add_raw(tb + ".norm3.weight", {C}); t.n3b = u->add_raw(tb + ".norm3.bias", {C});
-    t.ff1w = u->alloc(pf_unet::gemm_floats(1, C, 8 * C));
+    t.ff1w = u->alloc(pf_unet::gemm_alloc(1, C, 8 * C));
     u->add(tb + ".ff.net.0.proj.weight", {8 * C, C}).dests.push_back(Dest{D_GEGLU_W, t.ff1w, 1, C, 8 * C, 8 * C, 0});
     t.ff1b = u->alloc((size_t)8 * C);
     u->add(tb + ".ff.net.0.proj.bias", {8 * C}).dests.push_back(Dest{D_GEGLU_B, t.ff1b, 1, 0, 8 * C, 8 * C, 0});
@@ -324,11 +327,17 @@ static int pack_one(const ParamSpec& ps, const float* src, float* blob) {
     float* dst = blob + d.off;
     switch (d.kind) {
       case D_RAW: memcpy(dst, src, numel * sizeof(float)); break;
-      case D_GEMM: pack_gemm(dst, src, d.N, d.K, d.taps, d.Npad, d.n_off); break;
+      case D_GEMM:
+        pack_gemm(dst, src, d.N, d.K, d.taps, d.Npad, d.n_off);
+        if (d.K % 8 == 0) pack_gemm_bf3(dst + (size_t)d.taps * d.K * d.Npad, src, d.N, d.K, d.taps, d.Npad, d.n_off, nullptr);
+        break;
       case D_GEGLU_W: {
         const int inner = d.N / 2;
         for (int n = 0; n < d.N; ++n)
           for (int k = 0; k < d.K; ++k) dst[((size_t)(k / 4) * d.Npad + geglu_col(n, inner)) * 4 + (k & 3)] = src[(size_t)n * d.K + k];
+        std::vector<int> cm(d.N);
+        for (int n = 0; n < d.N; ++n) cm[n] = geglu_col(n, inner);
+        pack_gemm_bf3(dst + (size_t)d.K * d.Npad, src, d.N, d.K, 1, d.Npad, 0, cm.data());
         break;
       }
       case D_GEGLU_B: {
@@ -382,9 +391,16 @@ struct Ctx {
     (void)hipEventRecord(u->ev[(size_t)u->n_prof * 2 + 1], s);
     ++u->n_prof;
   }
-  void conv(const pf_conv_args& a, int kind) {
+  void conv(pf_conv_args a, int kind) {
     prof_begin(kind, conv_flops(a));
-    if (!dry && rc == PF_OK) rc = launch_conv(a, s);
+    if (!dry && rc == PF_OK) {
+      const int cin = a.c0 + a.c1;
+      if (u->precision == PF_PREC_BF16X3 && cin % 32 == 0) {  // second half of the weight region = bf16x3 packing
+        a.precision = PF_PREC_BF16X3;
+        a.w = a.w + (size_t)a.ks * a.ks * cin * ((a.n + 63) / 64 * 64);
+      }
+      rc = launch_conv(a, s);
+    }
     prof_end();
   }
   void gn(const float* x0, int c0, const float* x1, int c1, int hw, float eps, size_t g, size_t b_, float* sc, float* sh) {
@@ -737,6 +753,13 @@ int pf_unet_forward(pf_unet* u, const float* x, const int64_t* t, const float* c
   return run(u, c, x, t, cond, eps);
 }
 
+int pf_unet_set_precision(pf_unet* u, int precision) {
+  PF_REQUIRE(u && (precision == PF_PREC_F32 || precision == PF_PREC_BF16X3), "pf_unet_set_precision: bad arguments");
+  u->precision = precision;
+  return PF_OK;
+}
+int pf_unet_get_precision(const pf_unet* u) { return u ? u->precision : -1; }
+
 int pf_unet_set_profiling(pf_unet* u, int enabled) {
   PF_REQUIRE(u, "null handle");
   u->profiling = enabled != 0;
@@ -761,6 +784,13 @@ int pf_pack_gemm_weight(const float* w, int n, int k, int taps, float* dst) {
   PF_REQUIRE(w && dst && n > 0 && k > 0 && k % 4 == 0 && (taps == 1 || taps == 9), "pf_pack_gemm_weight: bad arguments");
   memset(dst, 0, pf_unet::gemm_floats(taps, k, n) * sizeof(float));
   pack_gemm(dst, w, n, k, taps, (n + 63) / 64 * 64, 0);
+  return PF_OK;
+}
+
+int pf_pack_gemm_weight_bf16x3(const float* w, int n, int k, int taps, void* dst) {
+  PF_REQUIRE(w && dst && n > 0 && k > 0 && k % 8 == 0 && (taps == 1 || taps == 9), "pf_pack_gemm_weight_bf16x3: bad arguments");
+  memset(dst, 0, pf_unet::gemm_floats(taps, k, n) * sizeof(float));
+  pack_gemm_bf3(dst, w, n, k, taps, (n + 63) / 64 * 64, 0, nullptr);
   return PF_OK;
 }
 

@@ -140,6 +140,17 @@ class UNetModel:
 
     __call__ = forward
 
+    # ---- arithmetic mode ------------------------------------------------------------------------
+    def set_precision(self, mode: str):
+        """"f32" (exact fp32 MFMA) or "bf16x3" (error-compensated split on the bf16 matrix pipe)."""
+        code = {"f32": 0, "bf16x3": 1}[mode]
+        _lib.check(self._lib.pf_unet_set_precision(self._h, code), "pf_unet_set_precision")
+        return self
+
+    @property
+    def precision(self) -> str:
+        return ["f32", "bf16x3"][self._lib.pf_unet_get_precision(self._h)]
+
     # ---- profiling ------------------------------------------------------------------------------
     def set_profiling(self, on: bool):
         _lib.check(self._lib.pf_unet_set_profiling(self._h, int(on)))

@@ -1,0 +1,133 @@
+"""bf16x3 split-MFMA mode (-m gpu): same kernels' contract as the fp32 MFMA path, looser per-op
+tolerance (products carry ~1e-5 relative error), and the whole-UNet contract of BASELINE.json
+(max-abs-diff < 1e-3 vs the reference) checked against the reference goldens."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from polyffusion_amd import _lib, synth  # noqa: E402
+from polyffusion_amd.arch import UNetConfig  # noqa: E402
+from polyffusion_amd.unet import UNetModel  # noqa: E402
+from polyffusion_amd.weights import synth_unet_state  # noqa: E402
+from test_gpu_ops import dev, gn_scale_shift, nhwc, rnd, run_conv  # noqa: E402
+
+TOL_OP = 3e-4  # on O(1) outputs; expected ~3e-5
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.require_gpu()
+    return _lib.load()
+
+
+def pack3(lib, w):
+    n, k = w.shape[0], w.shape[1]
+    taps = 9 if w.dim() == 4 and w.shape[2] == 3 else 1
+    dst = torch.zeros(lib.pf_packed_gemm_weight_floats(n, k, taps), dtype=torch.float32)
+    _lib.check(lib.pf_pack_gemm_weight_bf16x3(w.contiguous().data_ptr(), n, k, taps, dst.data_ptr()))
+    return dst.cuda()
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,cout", [(2, 32, 32, 64, 0, 64), (1, 16, 16, 256, 128, 256), (2, 8, 8, 32, 32, 32),
+                                               (16, 16, 16, 256, 256, 256), (1, 128, 128, 64, 0, 64), (3, 12, 20, 64, 32, 96)])
+def test_resblock_conv_gn_silu_bf16x3(lib, B, H, W, c0, c1, cout):
+    cin = c0 + c1
+    x = rnd((B, cin, H, W), 1) * 1.5 + 0.3
+    w, bias = rnd((cout, cin, 3, 3), 2, (1.0 / (cin * 9)) ** 0.5), rnd((cout,), 3, 0.1)
+    gamma, beta = 1 + 0.1 * rnd((cin,), 4), 0.1 * rnd((cin,), 5)
+    sb, res = rnd((B, cout), 6), rnd((B, cout, H, W), 7)
+    ref = F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-5)), w, bias, padding=1) + sb[:, :, None, None] + res
+    x0 = dev(nhwc(x[:, :c0]))
+    x1 = dev(nhwc(x[:, c0:])) if c1 else None
+    sc, sh = gn_scale_shift(lib, x0, x1, dev(gamma), dev(beta), 1e-5)
+    out = torch.empty(B, H, W, cout, device="cuda")
+    run_conv(lib, x0=x0, c0=c0, x1=x1, c1=c1, batch=B, hin=H, win=W, ks=3, stride=1, ups=0, w=pack3(lib, w), n=cout,
+             prologue=1, sc=sc, sh=sh, bias=dev(bias), sbias=dev(sb), ld_sbias=cout, res=dev(nhwc(res)), ld_res=cout,
+             out=out, ld_out=cout, precision=1)
+    err = (out.cpu() - nhwc(ref)).abs().max().item()
+    assert err < TOL_OP, err
+
+
+@pytest.mark.parametrize("B,H,W,c", [(2, 32, 32, 64), (1, 64, 64, 128), (4, 16, 16, 256), (1, 10, 18, 32)])
+def test_downsample_upsample_bf16x3(lib, B, H, W, c):
+    x = rnd((B, c, H, W), 11)
+    w, bias = rnd((c, c, 3, 3), 12, (1.0 / (c * 9)) ** 0.5), rnd((c,), 13, 0.1)
+    xd, wp = dev(nhwc(x)), pack3(lib, w)
+    ref = F.conv2d(x, w, bias, stride=2, padding=1)
+    out = torch.empty(B, ref.shape[2], ref.shape[3], c, device="cuda")
+    run_conv(lib, x0=xd, c0=c, batch=B, hin=H, win=W, ks=3, stride=2, ups=0, w=wp, n=c, bias=dev(bias), out=out, ld_out=c, precision=1)
+    assert (out.cpu() - nhwc(ref)).abs().max() < TOL_OP
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, bias, padding=1)
+    out = torch.empty(B, 2 * H, 2 * W, c, device="cuda")
+    run_conv(lib, x0=xd, c0=c, batch=B, hin=H, win=W, ks=3, stride=1, ups=1, w=wp, n=c, bias=dev(bias), out=out, ld_out=c, precision=1)
+    assert (out.cpu() - nhwc(ref)).abs().max() < TOL_OP
+
+
+@pytest.mark.parametrize("B,L,k0,k1,n", [(2, 1024, 256, 0, 256), (16, 256, 256, 0, 768), (3, 100, 64, 32, 32),
+                                          (1, 16384, 128, 64, 64), (2, 64, 1024, 0, 256), (1, 7, 32, 0, 160)])
+def test_linear_bf16x3(lib, B, L, k0, k1, n):
+    K = k0 + k1
+    x = rnd((B, L, K), 21)
+    w, bias, res, sb = rnd((n, K), 22, K ** -0.5), rnd((n,), 23, 0.1), rnd((B, L, n), 24), rnd((B, n), 25)
+    ref = F.linear(x, w, bias) + res + sb[:, None, :]
+    out = torch.empty(B, L, n, device="cuda")
+    run_conv(lib, x0=dev(x[..., :k0]), c0=k0, x1=dev(x[..., k0:]) if k1 else None, c1=k1, batch=B, hin=1, win=L, ks=1,
+             stride=1, ups=0, w=pack3(lib, w), n=n, bias=dev(bias), res=dev(res), ld_res=n, sbias=dev(sb), ld_sbias=n,
+             out=out, ld_out=n, precision=1)
+    assert (out.cpu() - ref).abs().max() < TOL_OP
+
+
+def test_layernorm_prologue_bf16x3(lib):
+    B, L, c = 2, 1024, 256
+    x = rnd((B, L, c), 41) * 1.7 - 0.4
+    gamma, beta = 1 + 0.1 * rnd((c,), 42), 0.1 * rnd((c,), 43)
+    w = rnd((3 * c, c), 44, c ** -0.5)
+    ref = F.linear(F.layer_norm(x, (c,), gamma, beta), w)
+    xd = dev(x)
+    mu, rs = torch.empty(B * L, device="cuda"), torch.empty(B * L, device="cuda")
+    _lib.check(lib.pf_ln_stats(xd.data_ptr(), B * L, c, 1e-5, mu.data_ptr(), rs.data_ptr(), _lib.current_stream()))
+    out = torch.empty(B, L, 3 * c, device="cuda")
+    run_conv(lib, x0=xd, c0=c, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, w), n=3 * c, prologue=3,
+             sc=dev(gamma), sh=dev(beta), mean=mu, rstd=rs, out=out, ld_out=3 * c, precision=1)
+    assert (out.cpu() - ref).abs().max() < TOL_OP
+
+
+def _make(cfg, h, w):
+    m = UNetModel(in_channels=cfg.in_channels, out_channels=cfg.out_channels, channels=cfg.channels,
+                  n_res_blocks=cfg.n_res_blocks, attention_levels=cfg.attention_levels,
+                  channel_multipliers=cfg.channel_multipliers, n_heads=cfg.n_heads, tf_layers=cfg.tf_layers,
+                  d_cond=cfg.d_cond, img_h=h, img_w=w)
+    m.load_state_dict(synth_unet_state(cfg, 0))
+    return m.set_precision("bf16x3")
+
+
+def test_full_unet_bf16x3_meets_the_contract(golden):
+    """BASELINE.json: UNet output max-abs-diff < 1e-3 vs the reference on identical (x_t, t, cond)."""
+    g = golden("unet_chd8bar_b2.npz")
+    m = _make(UNetConfig(d_cond=512), 128, 128)
+    assert m.precision == "bf16x3"
+    x = torch.from_numpy(synth.gaussian((2, 2, 128, 128), int(g["x_seed"]))).cuda()
+    c = torch.from_numpy(synth.gaussian((2, 1, 512), int(g["cond_seed"]))).cuda()
+    o = m(x, torch.from_numpy(g["t"]).cuda(), c).cpu().numpy()
+    err = np.abs(o - g["out"]).max()
+    rms = float(np.sqrt(((o - g["out"]) ** 2).mean()))
+    print(f"bf16x3 chd8bar B=2: max-abs-diff {err:.3e}, rms {rms:.3e}")
+    assert err < 5e-4, err   # half the contract bar
+    m.set_precision("f32")
+    o32 = m(x, torch.from_numpy(g["t"]).cuda(), c).cpu().numpy()
+    assert np.abs(o32 - g["out"]).max() < 1e-4
+
+
+def test_small_unet_bf16x3_vs_reference_golden(golden):
+    SMALL = UNetConfig(in_channels=2, out_channels=2, channels=32, n_res_blocks=1, attention_levels=(1,),
+                       channel_multipliers=(1, 2), n_heads=2, tf_layers=1, d_cond=32)
+    g = golden("unet_small.npz")
+    m = _make(SMALL, 32, 32)
+    x, t = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda()
+    assert np.abs(m(x, t, torch.from_numpy(g["cond1"]).cuda()).cpu().numpy() - g["out1"]).max() < 5e-4
+    assert np.abs(m(x, t, torch.from_numpy(g["cond4"]).cuda()).cpu().numpy() - g["out4"]).max() < 5e-4
