@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
   constexpr int NW = TOTW / 256;
   constexpr int TAPS = KS * KS;
   constexpr int NABUF = (KS == 1) ? 2 : 1;
+  constexpr int WRING = (KS == 1) ? 2 : 3;   // W tile buffers (3x3: direct-to-LDS ring, prefetch WRING-1 tiles ahead)
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int FM = WM / 32, FN = WN / 32;
   constexpr int PAD = (KS == 3) ? 1 : 0;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* sAh = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sAl = sAh + APLANE;
-  __bf16* sW = sAl + APLANE;               // [2 bufs][2 planes][4][BN][8]
+  __bf16* sW = sAl + APLANE;               // [WRING bufs][4 k8][2 planes][BN][8]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -151,21 +152,39 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
     }
   };
   auto loadW = [&](int chunk, int tap) {
-    const size_t k8b = (size_t)tap * K8 + (size_t)chunk * 4;
+    const size_t toff = ((size_t)tap * K8 + (size_t)chunk * 4) * ((size_t)2 * p.Npad * 8);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int u = tid + j * 256;
       const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
-      rw[j] = *reinterpret_cast<const u32x4*>(p.w + ((((k8b + k8l) * 2 + plane) * p.Npad) + n0 + n) * 8);
+      rw[j] = *reinterpret_cast<const u32x4*>(p.w + ((size_t)(k8l * 2 + plane) * p.Npad + n0 + n) * 8 + toff);
     }
   };
   auto storeW = [&](int buf) {
     __bf16* dst = sW + buf * (TOTW * 8);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      const int u = tid + j * 256;
-      const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
-      *reinterpret_cast<u32x4*>(dst + ((plane * 4 + k8l) * BN + n) * 8) = rw[j];
+      *reinterpret_cast<u32x4*>(dst + (tid + j * 256) * 8) = rw[j];
+    }
+  };
+
+  // direct global->LDS copy of one weight tile (no registers, no transform): LDS image = tile order, lane-linear
+  // per-thread source pointers of the NW pieces inside a tile are fixed; a tile only adds a wave-uniform offset
+  const __bf16* gw[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int u = tid + j * 256;
+    const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
+    gw[j] = p.w + ((size_t)(k8l * 2 + plane) * p.Npad + n0 + n) * 8;
+  }
+  const size_t wrow = (size_t)2 * p.Npad * 8;   // bf16 elements per k8 row pair (hi|lo planes)
+  auto gldsW = [&](int chunk, int tap, int buf) {
+    const size_t toff = ((size_t)tap * K8 + (size_t)chunk * 4) * wrow;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      __bf16* l = sW + buf * (TOTW * 8) + (wave * 64 + j * 256) * 8;   // wave-uniform base; the hardware adds lane*16 B
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[j] + toff),
+                                       (__attribute__((address_space(3))) void*)l, 16, 0, 0);
     }
   };
 
@@ -176,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
     const int py = pp / TW, px = pp % TW;
     hbase[fm] = ((py * STRIDE) * TWIN + px * STRIDE) * PITCH + 8 * (lane >> 5);
   }
-  const int wbase = ((lane >> 5) * BN + wn * WN + (lane & 31)) * 8;
+  const int wbase = ((lane >> 5) * 2 * BN + wn * WN + (lane & 31)) * 8;
 
   f32x16 acc[FM][FN];
 #pragma unroll
@@ -188,21 +207,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
 
   const int nchunk = cin / BK;
 
-  loadA(0); loadW(0, 0);
-  storeA(0); storeW(0);
-  __syncthreads();
-
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    const int nchunk1 = min(chunk + 1, nchunk - 1);
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int wpar = (chunk * TAPS + tap) & 1;
-      if (tap + 1 < TAPS) loadW(chunk, tap + 1); else loadW(nchunk1, 0);
-      if (tap == (TAPS >= 3 ? TAPS - 3 : 0)) loadA(nchunk1);
-
-      const int abuf = (NABUF == 2) ? (chunk & 1) : 0;
-      const int aoff = abuf * (NPIX * PITCH) + ((tap / KS) * TWIN + (tap % KS)) * PITCH;
-      const __bf16* cW = sW + wpar * (TOTW * 8) + wbase;
+  if constexpr (KS == 1) {
+    // 1x1 / linear: A and W tiles both change every chunk; register-staged, double-buffered, one barrier per chunk
+    loadA(0); loadW(0, 0);
+    storeA(0); storeW(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      const int nchunk1 = min(chunk + 1, nchunk - 1);
+      loadW(nchunk1, 0);
+      loadA(nchunk1);
+      const int aoff = (chunk & 1) * (NPIX * PITCH);
+      const __bf16* cW = sW + (chunk & 1) * (TOTW * 8) + wbase;
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
         bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
@@ -213,8 +228,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
         }
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) {
-          bh[fn] = *reinterpret_cast<const bf16x8*>(cW + ((2 * s) * BN + fn * 32) * 8);
-          bl[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 + 2 * s) * BN + fn * 32) * 8);
+          bh[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s) * BN + fn * 32) * 8);
+          bl[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s + 1) * BN + fn * 32) * 8);
         }
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm)
@@ -229,22 +244,103 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
 #pragma unroll
           for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
       }
-
-      storeW(wpar ^ 1);
-      if (NABUF == 2) {
-        storeA((chunk + 1) & 1);
-        __syncthreads();
-      } else {
-        __syncthreads();
-        if (tap == TAPS - 1) {   // every wave has finished reading this chunk's halo: overwrite it
-          storeA(0);
-          __syncthreads();
+      storeW((chunk + 1) & 1);
+      storeA((chunk + 1) & 1);
+      __syncthreads();
+    }
+  } else {
+    // 3x3: the halo image changes every 9 taps (register-staged, transformed, single buffer); weight tiles stream
+    // through a WRING-deep LDS ring by direct global->LDS loads issued D = WRING-1 tiles ahead.  Waits are counted:
+    // a thread's vmcnt only drains down to the (D-1) newest tiles, so D-1 tiles stay in flight across every barrier.
+    constexpr int D = WRING - 1;
+    const int ntile = nchunk * TAPS;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { const int t = min(d, ntile - 1); gldsW(t / TAPS, t % TAPS, d); }
+    loadA(0);
+    storeA(0);
+    int it = 0;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      const int nchunk1 = min(chunk + 1, nchunk - 1);
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap, ++it) {
+        // tile `it` is complete once at most (D-1)*NW of this thread's newer loads are outstanding (any extra ordinary
+        // loads issued since only make the wait stricter); the barrier then publishes every wave's part and also
+        // guarantees that every wave has finished reading tile it-1, whose buffer is refilled right after it.
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * NW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+          const int t = min(it + D, ntile - 1);
+          gldsW(t / TAPS, t % TAPS, (it + D) % WRING);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap == 0 && chunk + 1 < nchunk) loadA(chunk + 1);
+        const int aoff = ((tap / KS) * TWIN + (tap % KS)) * PITCH;
+        const __bf16* cW = sW + (it % WRING) * (TOTW * 8) + wbase;
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+          ah[fm] = *reinterpret_cast<const bf16x8*>(sAh + aoff + hbase[fm] + s * 16);
+          al[fm] = *reinterpret_cast<const bf16x8*>(sAl + aoff + hbase[fm] + s * 16);
+        }
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+          bh[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s) * BN + fn * 32) * 8);
+          bl[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s + 1) * BN + fn * 32) * 8);
+        }
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+      }
+        if (tap == TAPS - 1 && chunk + 1 < nchunk) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();   // every wave has finished reading this chunk's halo
+          storeA(0);                      // visible to all after the next iteration's barrier (lgkmcnt(0) precedes it)
         }
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail prefetches before the workgroup retires
   }
 
   const float* sb = p.sbias ? p.sbias + (size_t)b * p.ld_sbias : nullptr;
+  const bool full = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (n0 + BN <= p.N) && !p.geglu;
+  if (full) {
+    // interior tile: no per-element bounds checks, hoisted per-column terms
+    const size_t mbase = ((size_t)b * p.Hout + oy0) * p.Wout + ox0;
+    float cb[FN];
+    int ncol[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+      ncol[fn] = n0 + wn * WN + fn * 32 + (lane & 31);
+      cb[fn] = (p.bias ? p.bias[ncol[fn]] : 0.f) + (sb ? sb[ncol[fn]] : 0.f);
+    }
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int pp = wm * WM + fm * 32 + row;
+        const size_t m = mbase + (size_t)(pp / TW) * p.Wout + (pp % TW);
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+          float v = acc[fm][fn][r] + cb[fn];
+          if (p.res) v += p.res[m * p.ld_res + ncol[fn]];
+          p.out[m * p.ld_out + ncol[fn]] = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int fm = 0; fm < FM; ++fm) {
 #pragma unroll
@@ -285,7 +381,8 @@ template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO>
 static int launch3_cfg(ConvP3& p, hipStream_t stream) {
   constexpr int THIN = (TH - 1) * STRIDE + KS, TWIN = (TW - 1) * STRIDE + KS;
   constexpr int NABUF = (KS == 1) ? 2 : 1;
-  constexpr size_t lds = (size_t)(2 * NABUF * THIN * TWIN * 40 + 2 * 8 * BN * 8) * 2;
+  constexpr int WRING = (KS == 1) ? 2 : 3;
+  constexpr size_t lds = (size_t)(2 * NABUF * THIN * TWIN * 40 + WRING * 8 * BN * 8) * 2;
   static_assert(lds <= 160 * 1024, "LDS budget");
   p.tiles_x = cdiv(p.Wout, TW);
   p.tiles_y = cdiv(p.Hout, TH);
