@@ -165,7 +165,13 @@ typedef struct pf_conv_args {
   int32_t geglu;
   float* out; int32_t ld_out;
   int32_t precision;                                         /* PF_PREC_F32 (w = fp32 packing) | PF_PREC_BF16X3 (w = bf16x3 packing) */
+  float* stats_out;                                          /* optional [B][tiles][N][2] per-tile (sum, sumsq) of the outputs; see pf_conv_stats_tiles */
 } pf_conv_args;
+/* number of per-sample tiles a pf_conv2d launch with these arguments emits into stats_out (0 on error) */
+int pf_conv_stats_tiles(const pf_conv_args* a);
+/* GroupNorm scale/shift from per-tile statistics of up to two channel-concatenated producers (no pass over the tensors) */
+int pf_gn_finalize_tiles(const float* stats0, int tiles0, int c0, const float* stats1, int tiles1, int c1, int batch, int hw,
+                         int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 int pf_conv2d(const pf_conv_args* a, void* stream);
 
 /* softmax(q k^T * d_head^-0.5) v per (batch, head); q [B,Lq,*], k/v [B,Lk,*] with row strides ld*, heads packed

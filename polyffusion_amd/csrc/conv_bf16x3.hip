@@ -18,7 +18,7 @@
 //     consecutive-k B operands are one 16-byte LDS read per plane;
 //   * BK = 32; the 3x3 halo image is single-buffered (it changes every 9 taps; its global loads are
 //     issued three taps ahead), weight tiles are double-buffered; 1x1 mode double-buffers both.
-#include "pf_internal.h"
+#include "conv_common.h"
 
 namespace pf {
 
@@ -26,22 +26,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-struct ConvP3 {
-  const float* x0; const float* x1; int c0, c1;
-  int B, Hin, Win, Hout, Wout;
-  const __bf16* w; int N, Npad;
-  const float* sc; const float* sh; const float* mean; const float* rstd;
-  const float* bias; const float* sbias; int ld_sbias; const float* res; int ld_res;
-  int geglu;
-  float* out; int ld_out;
-  int tiles_x, tiles_y, nt;
-};
-
-__device__ __forceinline__ float silu3_f(float v) { return v / (1.0f + __expf(-v)); }
-__device__ __forceinline__ float gelu3_erf_f(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)); }
-
 template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO>
-__global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
+__global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP p) {
   constexpr int BK = 32;
   constexpr int BM = TH * TW;
   constexpr int THIN = (TH - 1) * STRIDE + KS;
@@ -140,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
             v = (v - pmu[i]) * prs[i] * vsc + vsh;
           } else {
             v = v * vsc + vsh;
-            if (PRO == 1) { v[0] = silu3_f(v[0]); v[1] = silu3_f(v[1]); v[2] = silu3_f(v[2]); v[3] = silu3_f(v[3]); }
+            if (PRO == 1) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
           }
         }
         const bf16x4 h = __builtin_convertvector(v, bf16x4);
@@ -157,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
     for (int j = 0; j < NW; ++j) {
       const int u = tid + j * 256;
       const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
-      rw[j] = *reinterpret_cast<const u32x4*>(p.w + ((size_t)(k8l * 2 + plane) * p.Npad + n0 + n) * 8 + toff);
+      rw[j] = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(p.w) + ((size_t)(k8l * 2 + plane) * p.Npad + n0 + n) * 8 + toff);
     }
   };
   auto storeW = [&](int buf) {
@@ -175,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
   for (int j = 0; j < NW; ++j) {
     const int u = tid + j * 256;
     const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
-    gw[j] = p.w + ((size_t)(k8l * 2 + plane) * p.Npad + n0 + n) * 8;
+    gw[j] = static_cast<const __bf16*>(p.w) + ((size_t)(k8l * 2 + plane) * p.Npad + n0 + n) * 8;
   }
   const size_t wrow = (size_t)2 * p.Npad * 8;   // bf16 elements per k8 row pair (hi|lo planes)
   auto gldsW = [&](int chunk, int tap, int buf) {
@@ -260,7 +246,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
     storeA(0);
     int it = 0;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-      const int nchunk1 = min(chunk + 1, nchunk - 1);
 #pragma unroll
       for (int tap = 0; tap < TAPS; ++tap, ++it) {
         // tile `it` is complete once at most (D-1)*NW of this thread's newer loads are outstanding (any extra ordinary
@@ -312,73 +297,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP3 p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail prefetches before the workgroup retires
   }
 
-  const float* sb = p.sbias ? p.sbias + (size_t)b * p.ld_sbias : nullptr;
-  const bool full = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (n0 + BN <= p.N) && !p.geglu;
-  if (full) {
-    // interior tile: no per-element bounds checks, hoisted per-column terms
-    const size_t mbase = ((size_t)b * p.Hout + oy0) * p.Wout + ox0;
-    float cb[FN];
-    int ncol[FN];
-#pragma unroll
-    for (int fn = 0; fn < FN; ++fn) {
-      ncol[fn] = n0 + wn * WN + fn * 32 + (lane & 31);
-      cb[fn] = (p.bias ? p.bias[ncol[fn]] : 0.f) + (sb ? sb[ncol[fn]] : 0.f);
-    }
-#pragma unroll
-    for (int fm = 0; fm < FM; ++fm) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int pp = wm * WM + fm * 32 + row;
-        const size_t m = mbase + (size_t)(pp / TW) * p.Wout + (pp % TW);
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) {
-          float v = acc[fm][fn][r] + cb[fn];
-          if (p.res) v += p.res[m * p.ld_res + ncol[fn]];
-          p.out[m * p.ld_out + ncol[fn]] = v;
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int fm = 0; fm < FM; ++fm) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int pp = wm * WM + fm * 32 + row;
-      const int oy = oy0 + pp / TW, ox = ox0 + pp % TW;
-      if (oy >= p.Hout || ox >= p.Wout) continue;
-      const size_t m = ((size_t)b * p.Hout + oy) * p.Wout + ox;
-      if (p.geglu) {
-        if (FN == 2) {
-          const int nv = n0 + wn * WN + (lane & 31);
-          const int j = (n0 + wn * WN) / 2 + (lane & 31);
-          if (j < p.N / 2) {
-            float v = acc[fm][0][r], g = acc[fm][FN - 1][r];
-            if (p.bias) { v += p.bias[nv]; g += p.bias[nv + 32]; }
-            p.out[m * p.ld_out + j] = v * gelu3_erf_f(g);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) {
-          const int n = n0 + wn * WN + fn * 32 + (lane & 31);
-          if (n < p.N) {
-            float v = acc[fm][fn][r];
-            if (p.bias) v += p.bias[n];
-            if (sb) v += sb[n];
-            if (p.res) v += p.res[m * p.ld_res + n];
-            p.out[m * p.ld_out + n] = v;
-          }
-        }
-      }
-    }
-  }
+  conv_epilogue<TH, TW, BN, FM, FN>(p, acc, b, oy0, ox0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem_raw));
 }
 
 template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO>
-static int launch3_cfg(ConvP3& p, hipStream_t stream) {
+static int launch3_cfg(ConvP& p, hipStream_t stream) {
   constexpr int THIN = (TH - 1) * STRIDE + KS, TWIN = (TW - 1) * STRIDE + KS;
   constexpr int NABUF = (KS == 1) ? 2 : 1;
   constexpr int WRING = (KS == 1) ? 2 : 3;
@@ -399,16 +322,8 @@ static int launch3_cfg(ConvP3& p, hipStream_t stream) {
   return PF_OK;
 }
 
-static int pick_tile3(int m_tiles128, int batch, int npad, bool geglu) {
-  if (geglu) return 0;
-  const int nt128 = cdiv(npad, 128), nt64 = cdiv(npad, 64);
-  if (npad >= 128 && npad % 128 == 0 && batch * m_tiles128 * nt128 >= 512) return 0;
-  if (batch * m_tiles128 * nt64 >= 512) return 1;
-  return 2;
-}
-
 template <int KS, int STRIDE, bool UPS, int PRO>
-static int dispatch_tile3(ConvP3& p, int tile, hipStream_t s) {
+static int dispatch_tile3(ConvP& p, int tile, hipStream_t s) {
   if constexpr (KS == 1) {
     if (tile == 0) return launch3_cfg<1, 1, false, 1, 128, 128, PRO>(p, s);
     if (tile == 1) return launch3_cfg<1, 1, false, 1, 128, 64, PRO>(p, s);
@@ -424,19 +339,17 @@ static int dispatch_tile3(ConvP3& p, int tile, hipStream_t s) {
 
 // same argument validation as launch_conv (done by the caller); w points to the bf16x3 packing
 int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
-  ConvP3 p;
+  ConvP p;
   p.x0 = a.x0; p.x1 = a.x1; p.c0 = a.c0; p.c1 = a.c1;
   p.B = a.batch; p.Hin = a.hin; p.Win = a.win;
   p.Hout = a.hin; p.Wout = a.win;
   if (a.ups) { p.Hout *= 2; p.Wout *= 2; }
   if (a.stride == 2) { p.Hout = (p.Hout - 1) / 2 + 1; p.Wout = (p.Wout - 1) / 2 + 1; }
-  p.w = reinterpret_cast<const __bf16*>(a.w); p.N = a.n; p.Npad = (a.n + 63) / 64 * 64;
+  p.w = a.w; p.N = a.n; p.Npad = (a.n + 63) / 64 * 64;
   p.sc = a.sc; p.sh = a.sh; p.mean = a.mean; p.rstd = a.rstd;
   p.bias = a.bias; p.sbias = a.sbias; p.ld_sbias = a.ld_sbias; p.res = a.res; p.ld_res = a.ld_res;
-  p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out;
-  int tile;
-  if (a.ks == 1) tile = pick_tile3(cdiv(p.Wout, 128), p.B * p.Hout, p.Npad, a.geglu != 0);
-  else tile = pick_tile3(cdiv(p.Hout, 8) * cdiv(p.Wout, 16), p.B, p.Npad, false);
+  p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out;
+  const int tile = conv_pick_tile(a);
   if (a.ks == 1) {
     switch (a.prologue) {
       case 0: return dispatch_tile3<1, 1, false, 0>(p, tile, stream);

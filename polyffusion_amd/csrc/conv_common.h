@@ -1,0 +1,124 @@
+// conv_common.h - kernel parameter block and the fused epilogue shared by conv_mfma.hip (fp32 MFMA)
+// and conv_bf16x3.hip (split bf16 MFMA).  Both kernels finish with the same 32x32 accumulator
+// fragments (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).
+#pragma once
+#include "pf_internal.h"
+
+namespace pf {
+
+struct ConvP {
+  const float* x0; const float* x1; int c0, c1;
+  int B, Hin, Win, Hout, Wout;
+  const void* w; int N, Npad;
+  const float* sc; const float* sh; const float* mean; const float* rstd;
+  const float* bias; const float* sbias; int ld_sbias; const float* res; int ld_res;
+  int geglu;
+  float* out; int ld_out;
+  float* stats;   // optional [B][tiles][N][2]: per-tile, per-channel (sum, sum of squares) of the stored outputs
+  int tiles_x, tiles_y, nt;
+};
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float gelu_erf_f(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)); }
+
+// out[m][n] = acc + bias[n] + sbias[b][n] + res[m][n]   (or the GeGLU product), NHWC store.
+// When p.stats is set, the workgroup also emits the per-channel sum / sum-of-squares of what it stored, so that the
+// GroupNorm that consumes this tensor needs no pass over it (deterministic: lane pair -> LDS -> one writer per channel).
+// `red` is LDS scratch of at least 4*BN floats that no wave is still reading (callers barrier before reuse).
+template <int TH, int TW, int BN, int FM, int FN>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][FN], int b, int oy0, int ox0, int n0,
+                                              int wm, int wn, int lane, int tid, float* red) {
+  constexpr int WM = TH * TW / 2, WN = BN / 2;
+  const float* sb = p.sbias ? p.sbias + (size_t)b * p.ld_sbias : nullptr;
+  const bool full = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (n0 + BN <= p.N) && !p.geglu;
+  float ssum[FN], ssq[FN];
+#pragma unroll
+  for (int fn = 0; fn < FN; ++fn) { ssum[fn] = 0.f; ssq[fn] = 0.f; }
+
+  if (full) {
+    // interior tile: no per-element bounds checks, hoisted per-column terms
+    const size_t mbase = ((size_t)b * p.Hout + oy0) * p.Wout + ox0;
+    float cb[FN];
+    int ncol[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+      ncol[fn] = n0 + wn * WN + fn * 32 + (lane & 31);
+      cb[fn] = (p.bias ? p.bias[ncol[fn]] : 0.f) + (sb ? sb[ncol[fn]] : 0.f);
+    }
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int pp = wm * WM + fm * 32 + row;
+        const size_t m = mbase + (size_t)(pp / TW) * p.Wout + (pp % TW);
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+          float v = acc[fm][fn][r] + cb[fn];
+          if (p.res) v += p.res[m * p.ld_res + ncol[fn]];
+          p.out[m * p.ld_out + ncol[fn]] = v;
+          ssum[fn] += v; ssq[fn] += v * v;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int pp = wm * WM + fm * 32 + row;
+        const int oy = oy0 + pp / TW, ox = ox0 + pp % TW;
+        if (oy >= p.Hout || ox >= p.Wout) continue;
+        const size_t m = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+        if (p.geglu) {
+          if (FN == 2) {
+            const int nv = n0 + wn * WN + (lane & 31);  // packed column of the value half; gate = nv + 32
+            const int j = (n0 + wn * WN) / 2 + (lane & 31);
+            if (j < p.N / 2) {
+              float v = acc[fm][0][r], g = acc[fm][FN - 1][r];
+              if (p.bias) { v += p.bias[nv]; g += p.bias[nv + 32]; }
+              p.out[m * p.ld_out + j] = v * gelu_erf_f(g);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn) {
+            const int n = n0 + wn * WN + fn * 32 + (lane & 31);
+            if (n < p.N) {
+              float v = acc[fm][fn][r];
+              if (p.bias) v += p.bias[n];
+              if (sb) v += sb[n];
+              if (p.res) v += p.res[m * p.ld_res + n];
+              p.out[m * p.ld_out + n] = v;
+              ssum[fn] += v; ssq[fn] += v * v;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (p.stats) {   // workgroup-uniform
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) { ssum[fn] += __shfl_xor(ssum[fn], 32); ssq[fn] += __shfl_xor(ssq[fn], 32); }
+    __syncthreads();   // nobody is still reading the main loop's LDS images
+    if (lane < 32) {
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) {
+        const int col = wn * WN + fn * 32 + lane;
+        red[(wm * BN + col) * 2 + 0] = ssum[fn];
+        red[(wm * BN + col) * 2 + 1] = ssq[fn];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      const int tile = (oy0 / TH) * p.tiles_x + ox0 / TW;
+      float* dst = p.stats + (((size_t)b * (p.tiles_x * p.tiles_y) + tile) * p.N + n0 + tid) * 2;
+      dst[0] = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
+      dst[1] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+    }
+  }
+}
+
+}  // namespace pf

@@ -19,23 +19,9 @@
 //   Arithmetic is v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain; the 1e-3 parity bar rules out
 //   bf16 inputs - SURVEY.md 0).  Both LDS images are double buffered and the next tile's global
 //   loads are in flight (registers) while the current tile's MFMAs run; one barrier per tile.
-#include "pf_internal.h"
+#include "conv_common.h"
 
 namespace pf {
-
-struct ConvP {
-  const float* x0; const float* x1; int c0, c1;
-  int B, Hin, Win, Hout, Wout;
-  const float* w; int N, Npad;
-  const float* sc; const float* sh; const float* mean; const float* rstd;
-  const float* bias; const float* sbias; int ld_sbias; const float* res; int ld_res;
-  int geglu;
-  float* out; int ld_out;
-  int tiles_x, tiles_y, nt;
-};
-
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
-__device__ __forceinline__ float gelu_erf_f(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)); }
 
 template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int BK, int PRO>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
@@ -149,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
     for (int j = 0; j < NW; ++j) {
       const int u = tid + j * 256;
       const int row = u / BN, col = u % BN;
-      rw[j] = *reinterpret_cast<const f32x4*>(p.w + ((krow0 + row) * p.Npad + n0 + col) * 4);
+      rw[j] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(p.w) + ((krow0 + row) * p.Npad + n0 + col) * 4);
     }
   };
   auto storeW = [&](int buf) {
@@ -218,42 +204,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
     }
   }
 
-  // ---- epilogue: bias / per-sample bias / residual / GeGLU, NHWC store ----
-  const float* sb = p.sbias ? p.sbias + (size_t)b * p.ld_sbias : nullptr;
-#pragma unroll
-  for (int fm = 0; fm < FM; ++fm) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int pp = wm * WM + fm * 32 + row;
-      const int oy = oy0 + pp / TW, ox = ox0 + pp % TW;
-      if (oy >= p.Hout || ox >= p.Wout) continue;
-      const size_t m = ((size_t)b * p.Hout + oy) * p.Wout + ox;
-      if (p.geglu) {
-        if (FN == 2) {
-          const int nv = n0 + wn * WN + (lane & 31);  // packed column of the value half; gate = nv + 32
-          const int j = (n0 + wn * WN) / 2 + (lane & 31);
-          if (j < p.N / 2) {
-            float v = acc[fm][0][r], g = acc[fm][FN - 1][r];
-            if (p.bias) { v += p.bias[nv]; g += p.bias[nv + 32]; }
-            p.out[m * p.ld_out + j] = v * gelu_erf_f(g);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) {
-          const int n = n0 + wn * WN + fn * 32 + (lane & 31);
-          if (n < p.N) {
-            float v = acc[fm][fn][r];
-            if (p.bias) v += p.bias[n];
-            if (sb) v += sb[n];
-            if (p.res) v += p.res[m * p.ld_res + n];
-            p.out[m * p.ld_out + n] = v;
-          }
-        }
-      }
-    }
-  }
+  // ---- epilogue: bias / per-sample bias / residual / GeGLU, NHWC store (+ optional GroupNorm partial statistics) ----
+  conv_epilogue<TH, TW, BN, FM, FN>(p, acc, b, oy0, ox0, n0, wm, wn, lane, tid, smem);
 }
 
 template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int BK, int PRO>
@@ -276,16 +228,34 @@ static int launch_cfg(ConvP& p, hipStream_t stream) {
   return PF_OK;
 }
 
-// tile choice: 0 = 128x128 (BK16), 1 = 128x64 (BK16), 2 = 64x64 (BK32)
-static int pick_tile(int m_rows_per_sample_tiles128, int m_tiles64, int batch, int npad, bool geglu) {
-  if (geglu) return 0;
-  const int nt128 = cdiv(npad, 128), nt64 = cdiv(npad, 64);
-  const int blocksA = batch * m_rows_per_sample_tiles128 * nt128;
-  const int blocksB = batch * m_rows_per_sample_tiles128 * nt64;
-  if (npad >= 128 && blocksA >= 512) return 0;
-  if (blocksB >= 512) return 1;
-  (void)m_tiles64;
+// tile choice shared by both arithmetic modes: 0 = 128 px x 128 ch, 1 = 128 px x 64 ch, 2 = 64 px x 64 ch
+static void conv_out_dims(const pf_conv_args& a, int* hout, int* wout) {
+  int h = a.hin, w = a.win;
+  if (a.ups) { h *= 2; w *= 2; }
+  if (a.stride == 2) { h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1; }
+  *hout = h; *wout = w;
+}
+int conv_pick_tile(const pf_conv_args& a) {
+  if (a.geglu) return 0;
+  int hout, wout;
+  conv_out_dims(a, &hout, &wout);
+  const int npad = (a.n + 63) / 64 * 64;
+  const int mt128 = a.ks == 1 ? a.batch * hout * cdiv(wout, 128) : a.batch * cdiv(hout, 8) * cdiv(wout, 16);
+  if (a.ks == 3 && a.stride == 2) return 2;
+  if (npad % 128 == 0 && mt128 * (npad / 128) >= 512) return 0;
+  if (mt128 * (npad / 64) >= 512) return 1;
   return 2;
+}
+void conv_tile_shape(const pf_conv_args& a, int tile, int* th, int* tw) {
+  if (a.ks == 1) { *th = 1; *tw = tile == 2 ? 64 : 128; }
+  else if (a.stride == 2) { *th = 4; *tw = 16; }
+  else { *th = tile == 2 ? 4 : 8; *tw = 16; }
+}
+int conv_stats_tiles(const pf_conv_args& a) {
+  int hout, wout, th, tw;
+  conv_out_dims(a, &hout, &wout);
+  conv_tile_shape(a, conv_pick_tile(a), &th, &tw);
+  return cdiv(hout, th) * cdiv(wout, tw);
 }
 
 template <int KS, int STRIDE, bool UPS, int PRO>
@@ -329,6 +299,7 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
   PF_REQUIRE(!(a.ks == 3 && a.prologue == 1 && (a.ups || a.stride == 2)), "conv: GN prologue only on plain 3x3");
   PF_REQUIRE(!(a.ks == 3 && a.prologue == 0 && !a.ups && a.stride == 1), "conv: plain 3x3 without prologue is not instantiated");
   PF_REQUIRE(!(a.ks == 1 && a.prologue == 1), "conv: 1x1 with SiLU prologue is not instantiated");
+  PF_REQUIRE(!(a.stats_out && a.geglu), "conv: statistics are not available with the GeGLU epilogue");
 
   PF_REQUIRE(a.precision == PF_PREC_F32 || a.precision == PF_PREC_BF16X3, "conv: bad precision %d", a.precision);
   if (a.precision == PF_PREC_BF16X3) return launch_conv_bf3(a, stream);
@@ -342,15 +313,9 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
   p.w = a.w; p.N = a.n; p.Npad = (a.n + 63) / 64 * 64;
   p.sc = a.sc; p.sh = a.sh; p.mean = a.mean; p.rstd = a.rstd;
   p.bias = a.bias; p.sbias = a.sbias; p.ld_sbias = a.ld_sbias; p.res = a.res; p.ld_res = a.ld_res;
-  p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out;
+  p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out;
 
-  int tile;
-  if (a.ks == 1) {
-    tile = pick_tile(cdiv(p.Wout, 128), cdiv(p.Wout, 64), p.B * p.Hout, p.Npad, a.geglu != 0);
-  } else {
-    tile = pick_tile(cdiv(p.Hout, 8) * cdiv(p.Wout, 16), 0, p.B, p.Npad, false);
-  }
-  if (tile == 0 && p.Npad % 128 != 0) tile = 1;
+  const int tile = conv_pick_tile(a);
 
   if (a.ks == 1) {
     switch (a.prologue) {

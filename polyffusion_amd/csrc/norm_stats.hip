@@ -14,17 +14,19 @@
 
 namespace pf {
 
-static inline int gn_nsplit(int hw) {
+int gn_nsplit(int hw) {
   int n = hw / 256;
   if (n < 1) n = 1;
   if (n > 64) n = 64;
   return n;
 }
 
-size_t gn_scratch_bytes(int batch, int c, int hw) { return (size_t)batch * gn_nsplit(hw) * c * 2 * sizeof(double); }
+size_t gn_scratch_bytes(int batch, int c, int hw) { return (size_t)batch * gn_nsplit(hw) * c * 2 * sizeof(float); }
 
+// Statistics of a tensor whose producer did not emit them (the stem conv): same [B][splits][C][2] layout as the
+// per-tile statistics written by the conv epilogues, so one finalize kernel serves both.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x0, int c0, const float* __restrict__ x1,
-                                                         int c1, int hw, int nsplit, double* __restrict__ part) {
+                                                         int c1, int hw, int nsplit, float* __restrict__ part) {
   __shared__ double red[256 * 8];
   const int C = c0 + c1, CQ = C / 4, PL = 256 / CQ;
   const int s = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -49,24 +51,32 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     double a = 0.0, q = 0.0;
     const int cqq = c >> 2, ci = c & 3;
     for (int l = 0; l < PL; ++l) { a += red[(l * CQ + cqq) * 8 + ci]; q += red[(l * CQ + cqq) * 8 + 4 + ci]; }
-    double* dst = part + (((size_t)b * nsplit + s) * C + c) * 2;
-    dst[0] = a; dst[1] = q;
+    float* dst = part + (((size_t)b * nsplit + s) * C + c) * 2;
+    dst[0] = (float)a; dst[1] = (float)q;
   }
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, int C, int hw, int nsplit, int groups,
-                                                          float eps, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ scale,
-                                                          float* __restrict__ shift) {
+// scale/shift per (sample, channel) from per-tile (sum, sumsq) of one or two channel-concatenated producers.
+// fp64 accumulation over tiles and over the channels of a group; deterministic.
+__global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __restrict__ s0, int t0, int c0,
+                                                                const float* __restrict__ s1, int t1, int c1, int hw, int groups,
+                                                                float eps, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ scale,
+                                                                float* __restrict__ shift) {
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int C = c0 + c1;
   const int tpg = 256 / groups;  // threads per group (power of two, <= 64)
   const int g = tid / tpg, j = tid % tpg;
   const int gs = C / groups;
   double a = 0.0, q = 0.0;
-  for (int i = j; i < nsplit * gs; i += tpg) {
-    const int s = i / gs, c = g * gs + i % gs;
-    const double* src = part + (((size_t)b * nsplit + s) * C + c) * 2;
-    a += src[0]; q += src[1];
+  for (int ci = 0; ci < gs; ++ci) {
+    const int c = g * gs + ci;
+    const float* src; int T, cs, cl;
+    if (c < c0) { src = s0; T = t0; cs = c0; cl = c; } else { src = s1; T = t1; cs = c1; cl = c - c0; }
+    for (int t = j; t < T; t += tpg) {
+      const float2 v = *reinterpret_cast<const float2*>(src + (((size_t)b * T + t) * cs + cl) * 2);
+      a += v.x; q += v.y;
+    }
   }
   for (int off = tpg >> 1; off > 0; off >>= 1) { a += __shfl_xor(a, off); q += __shfl_xor(q, off); }
   const double cnt = (double)gs * hw;
@@ -82,20 +92,36 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
   }
 }
 
+int launch_gn_finalize_tiles(const float* s0, int t0, int c0, const float* s1, int t1, int c1, int batch, int hw, int groups,
+                             float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t stream) {
+  const int C = c0 + c1;
+  PF_REQUIRE(s0 && t0 > 0 && c0 > 0 && (c1 == 0 || (s1 && t1 > 0)), "gn_finalize: bad statistics inputs");
+  PF_REQUIRE(groups > 0 && 256 % groups == 0 && groups >= 4 && C % groups == 0, "gn: groups=%d unsupported for C=%d", groups, C);
+  hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(batch), dim3(256), 0, stream, s0, t0, c0, s1, t1, c1, hw, groups, eps, gamma,
+                     beta, scale, shift);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+int launch_gn_partial(const float* x0, int c0, const float* x1, int c1, int batch, int hw, float* stats, hipStream_t stream) {
+  const int C = c0 + c1;
+  PF_REQUIRE(x0 && c0 > 0 && c0 % 4 == 0 && c1 % 4 == 0 && (c1 == 0 || x1), "gn: bad inputs (c0=%d c1=%d)", c0, c1);
+  PF_REQUIRE(C <= 1024, "gn: at most 1024 channels (got %d)", C);
+  const int ns = gn_nsplit(hw);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(ns, batch), dim3(256), 0, stream, x0, c0, x1, c1, hw, ns, stats);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
 int launch_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batch, int hw, int groups, float eps,
                           const float* gamma, const float* beta, float* scale, float* shift, void* scratch,
                           size_t scratch_bytes, hipStream_t stream) {
   const int C = c0 + c1;
-  PF_REQUIRE(x0 && c0 > 0 && c0 % 4 == 0 && c1 % 4 == 0 && (c1 == 0 || x1), "gn: bad inputs (c0=%d c1=%d)", c0, c1);
-  PF_REQUIRE(C <= 1024, "gn: at most 1024 channels (got %d)", C);
-  PF_REQUIRE(groups > 0 && 256 % groups == 0 && groups >= 4 && C % groups == 0, "gn: groups=%d unsupported for C=%d", groups, C);
   PF_REQUIRE(scratch && scratch_bytes >= gn_scratch_bytes(batch, C, hw), "gn: scratch too small");
-  const int ns = gn_nsplit(hw);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(ns, batch), dim3(256), 0, stream, x0, c0, x1, c1, hw, ns, (double*)scratch);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, (const double*)scratch, C, hw, ns, groups, eps,
-                     gamma, beta, scale, shift);
-  PF_CHECK_HIP(hipGetLastError());
-  return PF_OK;
+  int rc = launch_gn_partial(x0, c0, x1, c1, batch, hw, (float*)scratch, stream);
+  if (rc) return rc;
+  return launch_gn_finalize_tiles((const float*)scratch, gn_nsplit(hw), C, nullptr, 0, 0, batch, hw, groups, eps, gamma, beta, scale,
+                                  shift, stream);
 }
 
 // One wave per row; two passes over the (L1/L2-resident) row: mean, then centred variance.

@@ -32,6 +32,9 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 int launch_conv(const pf_conv_args& a, hipStream_t stream);
 double conv_flops(const pf_conv_args& a);
 int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream);  // called by launch_conv after validation
+int conv_pick_tile(const pf_conv_args& a);                        // 0: 128px x 128ch, 1: 128px x 64ch, 2: 64px x 64ch
+void conv_tile_shape(const pf_conv_args& a, int tile, int* th, int* tw);
+int conv_stats_tiles(const pf_conv_args& a);                      // per-sample tiles emitted into stats_out
 void pack_gemm_bf3(void* dst, const float* src, int n_src, int K, int taps, int Npad, int n_off, const int* colmap);
 
 int launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
@@ -41,6 +44,11 @@ size_t gn_scratch_bytes(int batch, int c, int hw);
 int launch_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batch, int hw, int groups, float eps,
                           const float* gamma, const float* beta, float* scale, float* shift, void* scratch,
                           size_t scratch_bytes, hipStream_t stream);
+int launch_gn_finalize_tiles(const float* s0, int t0, int c0, const float* s1, int t1, int c1, int batch, int hw, int groups,
+                             float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t stream);
+// per-split (sum, sumsq) of an NHWC tensor in the tile-statistics layout [B][gn_nsplit(hw)][C][2] (for tensors whose producer emits none)
+int gn_nsplit(int hw);
+int launch_gn_partial(const float* x0, int c0, const float* x1, int c1, int batch, int hw, float* stats, hipStream_t stream);
 int launch_ln_stats(const float* x, int rows, int c, float eps, float* mean, float* rstd, hipStream_t stream);
 
 // stem / head convolutions (NCHW <-> NHWC at the ABI edge)

@@ -356,6 +356,12 @@ static int pack_one(const ParamSpec& ps, const float* src, float* blob) {
 }
 
 // ---- forward ----
+// A tensor in the workspace: NHWC data + (optionally) the per-tile channel statistics its producer emitted.
+struct Tn {
+  const float* d = nullptr; int c = 0;
+  const float* st = nullptr; int nt = 0;   // [B][nt][c][2] (sum, sumsq) or null
+};
+
 struct Ctx {
   pf_unet* u; hipStream_t s; bool dry;
   char* base; size_t persist_off, temp_base, temp_off, persist_max, temp_max;
@@ -363,7 +369,6 @@ struct Ctx {
   const float* W;
   int n_launch;
   int rc;
-  int cross_cmax;
 
   float* palloc(size_t nfloats) {
     size_t o = persist_off; persist_off += align_up(nfloats * 4, 256);
@@ -391,7 +396,15 @@ struct Ctx {
     (void)hipEventRecord(u->ev[(size_t)u->n_prof * 2 + 1], s);
     ++u->n_prof;
   }
-  void conv(pf_conv_args a, int kind) {
+  // launch a conv/linear; when `stats` is given, the producer also emits per-tile channel statistics for a later GroupNorm
+  // (buffer from the persistent or the temp region, matching the lifetime of the output tensor)
+  void conv(pf_conv_args a, int kind, Tn* stats = nullptr, bool persist = true) {
+    if (stats) {
+      const int nt = conv_stats_tiles(a);
+      float* sb = persist ? palloc((size_t)B * nt * a.n * 2) : talloc((size_t)B * nt * a.n * 2);
+      a.stats_out = sb;
+      stats->d = a.out; stats->c = a.n; stats->st = sb; stats->nt = nt;
+    }
     prof_begin(kind, conv_flops(a));
     if (!dry && rc == PF_OK) {
       const int cin = a.c0 + a.c1;
@@ -403,13 +416,21 @@ struct Ctx {
     }
     prof_end();
   }
-  void gn(const float* x0, int c0, const float* x1, int c1, int hw, float eps, size_t g, size_t b_, float* sc, float* sh) {
-    float* scratch = talloc(gn_scratch_bytes(B, c0 + c1, hw) / 4);
+  // GroupNorm scale/shift of concat(x0, x1) from the producers' tile statistics (no pass over the data)
+  void gn(const Tn& x0, const Tn& x1, int hw, float eps, size_t g, size_t b_, float* sc, float* sh) {
     prof_begin(PF_K_GNSTAT, 0.0);
     if (!dry && rc == PF_OK)
-      rc = launch_gn_scale_shift(x0, c0, x1, c1, B, hw, 32, eps, w(g), w(b_), sc, sh, scratch, gn_scratch_bytes(B, c0 + c1, hw), s);
+      rc = launch_gn_finalize_tiles(x0.st, x0.nt, x0.c, x1.st, x1.nt, x1.c, B, hw, 32, eps, w(g), w(b_), sc, sh, s);
     prof_end();
-    ++n_launch;  // two kernels
+  }
+  // statistics for a tensor whose producer emitted none (the stem conv output)
+  void gn_partial(Tn& x, int hw) {
+    const int ns = gn_nsplit(hw);
+    float* sb = palloc((size_t)B * ns * x.c * 2);
+    prof_begin(PF_K_GNSTAT, 0.0);
+    if (!dry && rc == PF_OK) rc = launch_gn_partial(x.d, x.c, nullptr, 0, B, hw, sb, s);
+    prof_end();
+    x.st = sb; x.nt = ns;
   }
   void ln(const float* x, int rows, int c, float* mu, float* rs) {
     prof_begin(PF_K_LNSTAT, 0.0);
@@ -427,39 +448,42 @@ static pf_conv_args conv_base(const float* x0, int c0, const float* x1, int c1, 
   return a;
 }
 
-static float* run_res(Ctx& c, const Layer& L, const float* x0, int c0, const float* x1, int c1, int H, int W_, const float* tb_all) {
+static Tn run_res(Ctx& c, const Layer& L, const Tn& x0, const Tn& x1, int H, int W_, const float* tb_all) {
   const int B = c.B, hw = H * W_, ci = L.cin, co = L.cout;
   float* out = c.palloc((size_t)B * hw * co);
   c.treset();
   float* sc1 = c.talloc((size_t)B * ci); float* sh1 = c.talloc((size_t)B * ci);
   float* h = c.talloc((size_t)B * hw * co);
   float* sc2 = c.talloc((size_t)B * co); float* sh2 = c.talloc((size_t)B * co);
-  c.gn(x0, c0, x1, c1, hw, 1e-5f, L.gn1_g, L.gn1_b, sc1, sh1);
+  c.gn(x0, x1, hw, 1e-5f, L.gn1_g, L.gn1_b, sc1, sh1);
+  Tn ht;
   {
-    pf_conv_args a = conv_base(x0, c0, x1, c1, B, H, W_, 3, c.w(L.w1), co, h);
+    pf_conv_args a = conv_base(x0.d, x0.c, x1.d, x1.c, B, H, W_, 3, c.w(L.w1), co, h);
     a.prologue = 1; a.sc = sc1; a.sh = sh1; a.bias = c.w(L.b1);
     a.sbias = c.dry ? nullptr : tb_all + L.emb_off; a.ld_sbias = c.u->sum_emb;
-    c.conv(a, PF_K_CONV3);
+    c.conv(a, PF_K_CONV3, &ht, false);
   }
-  c.gn(h, co, nullptr, 0, hw, 1e-5f, L.gn2_g, L.gn2_b, sc2, sh2);
-  const float* res = x0;
+  c.gn(ht, Tn{}, hw, 1e-5f, L.gn2_g, L.gn2_b, sc2, sh2);
+  const float* res = x0.d;
   if (ci != co) {
     float* sk = c.talloc((size_t)B * hw * co);
-    pf_conv_args a = conv_base(x0, c0, x1, c1, B, 1, hw, 1, c.w(L.wskip), co, sk);
+    pf_conv_args a = conv_base(x0.d, x0.c, x1.d, x1.c, B, 1, hw, 1, c.w(L.wskip), co, sk);
     a.bias = c.w(L.bskip);
     c.conv(a, PF_K_GEMM);
     res = sk;
   }
+  Tn ot;
   {
     pf_conv_args a = conv_base(h, co, nullptr, 0, B, H, W_, 3, c.w(L.w2), co, out);
     a.prologue = 1; a.sc = sc2; a.sh = sh2; a.bias = c.w(L.b2); a.res = res; a.ld_res = co;
-    c.conv(a, PF_K_CONV3);
+    c.conv(a, PF_K_CONV3, &ot, true);
   }
-  return out;
+  return ot;
 }
 
-static float* run_st(Ctx& c, const Layer& L, const float* x, int H, int W_, const float* cond, const float* cross_all) {
+static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const float* cond, const float* cross_all) {
   const int B = c.B, hw = H * W_, C = L.cin, M = B * hw, nh = c.u->cfg.n_heads, dh = C / nh, dc = c.u->cfg.d_cond;
+  const float* x = xin.d;
   float* out = c.palloc((size_t)M * C);
   c.treset();
   float* sc = c.talloc((size_t)B * C); float* sh = c.talloc((size_t)B * C);
@@ -470,7 +494,7 @@ static float* run_st(Ctx& c, const Layer& L, const float* x, int H, int W_, cons
   float* ff = c.talloc((size_t)M * 4 * C);
   float* kv = nullptr;
   if (c.n_cond > 1) kv = c.talloc((size_t)B * c.n_cond * 2 * C);
-  c.gn(x, C, nullptr, 0, hw, 1e-6f, L.norm_g, L.norm_b, sc, sh);
+  c.gn(xin, Tn{}, hw, 1e-6f, L.norm_g, L.norm_b, sc, sh);
   {
     pf_conv_args a = conv_base(x, C, nullptr, 0, B, 1, hw, 1, c.w(L.pin_w), C, ta);
     a.prologue = 2; a.sc = sc; a.sh = sh; a.bias = c.w(L.pin_b);
@@ -535,12 +559,13 @@ static float* run_st(Ctx& c, const Layer& L, const float* x, int H, int W_, cons
     }
     std::swap(t0, t2);
   }
+  Tn ot;
   {
     pf_conv_args a = conv_base(t0, C, nullptr, 0, B, 1, hw, 1, c.w(L.pout_w), C, out);
     a.bias = c.w(L.pout_b); a.res = x; a.ld_res = C;
-    c.conv(a, PF_K_GEMM);
+    c.conv(a, PF_K_GEMM, &ot, true);
   }
-  return out;
+  return ot;
 }
 
 static void small_launch(Ctx& c, int rc_in) { if (c.rc == PF_OK) c.rc = rc_in; }
@@ -554,7 +579,6 @@ static int run(pf_unet* u, Ctx& c, const float* x, const int64_t* t, const float
   float* tb_all = c.palloc((size_t)B * u->sum_emb);
   c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_time_embed(t, c.w(u->te_w0), c.w(u->te_b0), c.w(u->te_w2), c.w(u->te_b2), tsilu, B, cfg.channels, u->d_t, c.s)); c.prof_end();
   c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_matvec(tsilu, u->d_t, c.w(u->emb_w), c.w(u->emb_b), tb_all, u->sum_emb, B, u->sum_emb, u->d_t, c.s)); c.prof_end();
-  // n_cond == 1: per-sample cross-attention bias to_out(to_v(c)) for every transformer block
   float* cross_all = nullptr;  // [B][cross_total]: to_out(to_v(c)) + bias of every transformer block
   if (c.n_cond == 1 && u->cross_total > 0) {
     const int T = u->cross_total;
@@ -570,9 +594,9 @@ static int run(pf_unet* u, Ctx& c, const float* x, const int64_t* t, const float
     } else {
       auto each_tb = [&](const Layer& L) {
         if (L.kind != 2) return;
-        for (const Layer::TB& t : L.tbs) {
+        for (const Layer::TB& tb : L.tbs) {
           c.prof_begin(PF_K_SMALL, 0);
-          if (!c.dry) small_launch(c, launch_matvec(vtmp + t.cross_off, T, c.w(t.o2raw), c.w(t.o2b), cross_all + t.cross_off, T, B, L.cin, L.cin, c.s));
+          if (!c.dry) small_launch(c, launch_matvec(vtmp + tb.cross_off, T, c.w(tb.o2raw), c.w(tb.o2b), cross_all + tb.cross_off, T, B, L.cin, L.cin, c.s));
           c.prof_end();
         }
       };
@@ -582,62 +606,63 @@ static int run(pf_unet* u, Ctx& c, const float* x, const int64_t* t, const float
     }
   }
 
-  std::vector<const float*> skips;
-  std::vector<int> skip_c;
-  const float* cur = nullptr;
-  int cur_c = 0;
-  auto run_layers = [&](const Block& b, const float* in0, int c0, const float* in1, int c1) {
-    const float* a0 = in0; int ac0 = c0; const float* a1 = in1; int ac1 = c1;
+  std::vector<Tn> skips;
+  Tn cur;
+  auto run_layers = [&](const Block& b, Tn in0, Tn in1) {
+    Tn a0 = in0, a1 = in1;
     for (const Layer& L : b.layers) {
-      float* o = nullptr;
+      Tn o;
       switch (L.kind) {
         case 0: {
-          o = c.palloc((size_t)B * H * W_ * L.cout);
+          float* od = c.palloc((size_t)B * H * W_ * L.cout);
           c.prof_begin(PF_K_SMALL, 2.0 * B * H * W_ * 9.0 * L.cin * L.cout);
-          if (!c.dry) small_launch(c, launch_conv_in(x, c.w(u->in_w), c.w(u->in_b), o, B, L.cin, L.cout, H, W_, c.s));
+          if (!c.dry) small_launch(c, launch_conv_in(x, c.w(u->in_w), c.w(u->in_b), od, B, L.cin, L.cout, H, W_, c.s));
           c.prof_end();
+          o.d = od; o.c = L.cout;
+          c.gn_partial(o, H * W_);
           break;
         }
-        case 1: o = run_res(c, L, a0, ac0, a1, ac1, H, W_, tb_all); break;
+        case 1: o = run_res(c, L, a0, a1, H, W_, tb_all); break;
         case 2: o = run_st(c, L, a0, H, W_, cond, cross_all); break;
         case 3: {
-          o = c.palloc((size_t)B * (H / 2) * (W_ / 2) * L.cout);
-          pf_conv_args a = conv_base(a0, ac0, nullptr, 0, B, H, W_, 3, c.w(L.w1), L.cout, o);
+          float* od = c.palloc((size_t)B * (H / 2) * (W_ / 2) * L.cout);
+          pf_conv_args a = conv_base(a0.d, a0.c, nullptr, 0, B, H, W_, 3, c.w(L.w1), L.cout, od);
           a.stride = 2; a.bias = c.w(L.b1);
-          c.conv(a, PF_K_CONV3);
+          c.conv(a, PF_K_CONV3, &o, true);
           H /= 2; W_ /= 2;
           break;
         }
         case 4: {
-          o = c.palloc((size_t)B * (H * 2) * (W_ * 2) * L.cout);
-          pf_conv_args a = conv_base(a0, ac0, nullptr, 0, B, H, W_, 3, c.w(L.w1), L.cout, o);
+          float* od = c.palloc((size_t)B * (H * 2) * (W_ * 2) * L.cout);
+          pf_conv_args a = conv_base(a0.d, a0.c, nullptr, 0, B, H, W_, 3, c.w(L.w1), L.cout, od);
           a.ups = 1; a.bias = c.w(L.b1);
-          c.conv(a, PF_K_CONV3);
+          c.conv(a, PF_K_CONV3, &o, true);
           H *= 2; W_ *= 2;
           break;
         }
       }
-      a0 = o; ac0 = L.cout; a1 = nullptr; ac1 = 0;
+      if (c.dry) o.c = L.cout;
+      a0 = o; a1 = Tn{};
     }
-    cur = a0; cur_c = ac0;
+    cur = a0;
   };
 
   for (const Block& b : u->in_blocks) {
-    run_layers(b, cur, cur_c, nullptr, 0);
-    skips.push_back(cur); skip_c.push_back(cur_c);
+    run_layers(b, cur, Tn{});
+    skips.push_back(cur);
   }
-  run_layers(u->mid, cur, cur_c, nullptr, 0);
+  run_layers(u->mid, cur, Tn{});
   for (const Block& b : u->out_blocks) {
-    const float* sk = skips.back(); const int sc_ = skip_c.back();
-    skips.pop_back(); skip_c.pop_back();
-    run_layers(b, cur, cur_c, sk, sc_);  // channel order [x, skip] (unet.py:192)
+    const Tn sk = skips.back();
+    skips.pop_back();
+    run_layers(b, cur, sk);  // channel order [x, skip] (unet.py:192)
   }
   // out: GN + SiLU + conv3x3 -> NCHW
   c.treset();
-  float* sc = c.talloc((size_t)B * cur_c); float* sh = c.talloc((size_t)B * cur_c);
-  c.gn(cur, cur_c, nullptr, 0, H * W_, 1e-5f, u->out_g, u->out_b, sc, sh);
-  c.prof_begin(PF_K_SMALL, 2.0 * B * H * W_ * 9.0 * cur_c * cfg.out_channels);
-  if (!c.dry) small_launch(c, launch_conv_out(cur, sc, sh, c.w(u->out_w), c.w(u->out_bias), eps, B, cur_c, cfg.out_channels, H, W_, c.s));
+  float* sc = c.talloc((size_t)B * cur.c); float* sh = c.talloc((size_t)B * cur.c);
+  c.gn(cur, Tn{}, H * W_, 1e-5f, u->out_g, u->out_b, sc, sh);
+  c.prof_begin(PF_K_SMALL, 2.0 * B * H * W_ * 9.0 * cur.c * cfg.out_channels);
+  if (!c.dry) small_launch(c, launch_conv_out(cur.d, sc, sh, c.w(u->out_w), c.w(u->out_bias), eps, B, cur.c, cfg.out_channels, H, W_, c.s));
   c.prof_end();
   return c.rc;
 }
@@ -801,6 +826,12 @@ int pf_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batc
 }
 int pf_ln_stats(const float* x, int rows, int c, float eps, float* mean, float* rstd, void* stream) {
   return launch_ln_stats(x, rows, c, eps, mean, rstd, (hipStream_t)stream);
+}
+int pf_conv_stats_tiles(const pf_conv_args* a) { return a ? conv_stats_tiles(*a) : 0; }
+int pf_gn_finalize_tiles(const float* stats0, int tiles0, int c0, const float* stats1, int tiles1, int c1, int batch, int hw,
+                         int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
+  return launch_gn_finalize_tiles(stats0, tiles0, c0, stats1, tiles1, c1, batch, hw, groups, eps, gamma, beta, scale, shift,
+                                  (hipStream_t)stream);
 }
 int pf_conv2d(const pf_conv_args* a, void* stream) {
   PF_REQUIRE(a, "pf_conv2d: null argument");

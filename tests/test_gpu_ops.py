@@ -268,3 +268,48 @@ def test_errors_are_reported_not_ub(lib):
     assert lib.pf_conv2d(C.byref(a), None) < 0 and b"ks" in lib.pf_last_error()
     x = torch.zeros(4, device="cuda")
     assert lib.pf_attention(x.data_ptr(), 4, x.data_ptr(), 4, x.data_ptr(), 4, x.data_ptr(), 4, 1, 1, 48, 1, 1, None) < 0
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("B,H,W,c0,c1,cout", [(2, 32, 32, 64, 0, 64), (2, 12, 20, 64, 32, 96), (16, 16, 16, 256, 0, 256)])
+def test_producer_tile_statistics_feed_groupnorm(lib, precision, B, H, W, c0, c1, cout):
+    """A conv launch emits per-tile channel (sum, sumsq) of what it stores; pf_gn_finalize_tiles turns the statistics of
+    two producers (channel-concatenated) into the same scale/shift a pass over the data gives."""
+    cin = c0 + c1
+    x = rnd((B, cin, H, W), 1)
+    w, bias = rnd((cout, cin, 3, 3), 2, (1.0 / (cin * 9)) ** 0.5), rnd((cout,), 3, 0.1)
+    gamma, beta = 1 + 0.1 * rnd((cin,), 4), 0.1 * rnd((cin,), 5)
+    x0 = dev(nhwc(x[:, :c0]))
+    x1 = dev(nhwc(x[:, c0:])) if c1 else None
+    sc, sh = gn_scale_shift(lib, x0, x1, dev(gamma), dev(beta), 1e-5)
+    wp = pack_w(lib, w)
+    if precision == 1:
+        dst = torch.zeros(lib.pf_packed_gemm_weight_floats(cout, cin, 9), dtype=torch.float32)
+        _lib.check(lib.pf_pack_gemm_weight_bf16x3(w.contiguous().data_ptr(), cout, cin, 9, dst.data_ptr()))
+        wp = dst.cuda()
+    kw = dict(x0=x0, c0=c0, x1=x1, c1=c1, batch=B, hin=H, win=W, ks=3, stride=1, ups=0, w=wp, n=cout, prologue=1, sc=sc, sh=sh,
+              bias=dev(bias), precision=precision)
+    a = _lib.ConvArgs()
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+    nt = lib.pf_conv_stats_tiles(C.byref(a))
+    assert nt > 0
+    out = torch.empty(B, H, W, cout, device="cuda")
+    stats = torch.full((B, nt, cout, 2), float("nan"), device="cuda")
+    run_conv(lib, out=out, ld_out=cout, stats_out=stats, **kw)
+    o = out.cpu().double()
+    assert torch.isfinite(stats).all()
+    tot = stats.cpu().double().sum(1)  # [B, cout, 2]
+    assert (tot[..., 0] - o.sum((1, 2))).abs().max() < 1e-2
+    assert (tot[..., 1] - (o * o).sum((1, 2))).abs().max() < 1e-2
+    # GroupNorm of concat(out, out2) from statistics only
+    g2, b2 = 1 + 0.1 * rnd((2 * cout,), 8), 0.1 * rnd((2 * cout,), 9)
+    sc2, sh2 = torch.empty(B, 2 * cout, device="cuda"), torch.empty(B, 2 * cout, device="cuda")
+    g2d, b2d = dev(g2), dev(b2)  # keep alive across the launch
+    _lib.check(lib.pf_gn_finalize_tiles(stats.data_ptr(), nt, cout, stats.data_ptr(), nt, cout, B, H * W, 32, 1e-5,
+                                        g2d.data_ptr(), b2d.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), _lib.current_stream()))
+    torch.cuda.synchronize()
+    cat = torch.cat([out.cpu(), out.cpu()], dim=-1).permute(0, 3, 1, 2)
+    ref = F.group_norm(cat, 32, g2, b2, eps=1e-5)
+    got = cat * sc2.cpu()[:, :, None, None] + sh2.cpu()[:, :, None, None]
+    assert (ref - got).abs().max() < 5e-5
