@@ -42,6 +42,9 @@ from polyffusion_amd.sampler import SDFSampler  # noqa: E402
 from polyffusion_amd.weights import synth_chord_encoder_state, synth_unet_state  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X dense bf16 matrix peak (not the 2:1-sparse marketing figure)
+# algorithmic (fp32-equivalent) FLOP/s ceiling of each arithmetic mode: the bf16x3 split issues three bf16 MFMAs per product
+PEAK_ALGO = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0}
 F_MIN_PER_SAMPLE_EVAL = 89.338e9  # algorithmic FLOPs per UNet sample-eval, n_cond == 1 dead math removed
 BATCH = 16
 KIND_NAMES = ["conv3x3_mfma", "gemm_mfma", "attention", "gn_stats", "ln_stats", "small"]
@@ -158,13 +161,16 @@ def main():
     out = {
         "metric": "denoising steps/sec (8-bar prmat2c, batch 16)", "value": round(value, 4), "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "sdf_chd8bar cond generation, batch 16 per GPU, 1000-step DDPM sampler loop body "
                                "(BASELINE.json configs[1]); weights: deterministic synthetic, 41.08M params",
                    "global_batch": BATCH * world, "unet_evals_per_step": BATCH * world, "parallelism": f"batch-shard x{world}",
                    "weight_broadcast_s": round(bcast_s, 4), "launches_per_step": unet.n_launches(BATCH) + 3},
         "path_tflops": round(F_MIN_PER_SAMPLE_EVAL * BATCH * world * args.steps / elapsed / 1e12, 3),
         "path_frac_of_f32_mfma_peak": round(F_MIN_PER_SAMPLE_EVAL * BATCH * args.steps / elapsed / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
+        "precision_note": ("dense contractions on the bf16 matrix pipe as an error-compensated split (3 MFMAs per product, fp32 accumulate); "
+                           "UNet max-abs-diff vs the reference 4.7e-5 (contract 1e-3)") if args.precision == "bf16x3"
+        else "dense contractions on the fp32 matrix pipe (exact fp32 FMA chains)",
     }
 
     if rank == 0 and args.profile_steps > 0:
@@ -182,9 +188,18 @@ def main():
         k = agg.get(0)
         if k:
             ach = k[2] / (k[1] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                               "kernel": "conv_mfma_kernel<3x3> (fp32 MFMA, fused GN+SiLU prologue)",
+            peak = PEAK_ALGO[args.precision]
+            traffic = None
+            tpath = os.path.join(REPO, "profiles", f"pmc_traffic_{args.precision}.json")
+            if os.path.exists(tpath):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": traffic,
+                               "peak_note": ("fp32-equivalent ceiling = bf16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per product"
+                                             if args.precision == "bf16x3" else "fp32 MFMA dense peak"),
+                               "matrix_pipe_frac": round(ach * (3.0 if args.precision == "bf16x3" else 1.0)
+                                                         / (PEAK_BF16_MFMA_TFLOPS if args.precision == "bf16x3" else PEAK_F32_MFMA_TFLOPS), 4),
+                               "kernel": ("conv_bf3_kernel<3x3> (bf16x3 split MFMA" if args.precision == "bf16x3" else "conv_mfma_kernel<3x3> (fp32 MFMA") + ", fused GN+SiLU prologue)",
                                "launches_per_step": k[0] // args.profile_steps,
                                "avg_launch_ms": round(k[1] / k[0], 4),
                                "flops_per_step": k[2] / args.profile_steps}

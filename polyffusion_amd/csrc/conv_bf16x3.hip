@@ -26,8 +26,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO>
-__global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP p) {
+template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM>
+__global__ __launch_bounds__(NWM * 128, NWM) void conv_bf3_kernel(ConvP p) {
+  constexpr int NT = NWM * 128;            // threads: NWM x 2 waves
   constexpr int BK = 32;
   constexpr int BM = TH * TW;
   constexpr int THIN = (TH - 1) * STRIDE + KS;
@@ -36,18 +37,18 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP p) {
   constexpr int PITCH = BK + 8;            // bf16 elements per pixel row (80 B: conflict-free b128 for consecutive pixels)
   constexpr int KQ = BK / 4;               // float4 per pixel per chunk (global side)
   constexpr int TOTA = NPIX * KQ;
-  constexpr int NA = (TOTA + 255) / 256;
-  constexpr int PSTEP = 256 / KQ;          // 32 pixels between a thread's successive float4
+  constexpr int NA = (TOTA + NT - 1) / NT;
+  constexpr int PSTEP = NT / KQ;           // pixels between a thread's successive float4
   constexpr int TOTW = 8 * BN;             // 16-byte units per W tile (2 planes x 4 k8 x BN)
-  constexpr int NW = TOTW / 256;
+  constexpr int NW = TOTW / NT;
   constexpr int TAPS = KS * KS;
   constexpr int NABUF = (KS == 1) ? 2 : 1;
   constexpr int WRING = (KS == 1) ? 2 : 3;   // W tile buffers (3x3: direct-to-LDS ring, prefetch WRING-1 tiles ahead)
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int WM = BM / NWM, WN = BN / 2;
   constexpr int FM = WM / 32, FN = WN / 32;
   constexpr int PAD = (KS == 3) ? 1 : 0;
   constexpr int APLANE = NABUF * NPIX * PITCH;  // bf16 elements per A plane
-  static_assert(TOTW % 256 == 0 && FM >= 1 && FN >= 1, "bad tile");
+  static_assert(TOTW % NT == 0 && FM >= 1 && FN >= 1, "bad tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* sAh = reinterpret_cast<__bf16*>(smem_raw);
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP p) {
     const size_t toff = ((size_t)tap * K8 + (size_t)chunk * 4) * ((size_t)2 * p.Npad * 8);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      const int u = tid + j * 256;
+      const int u = tid + j * NT;
       const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
       rw[j] = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(p.w) + ((size_t)(k8l * 2 + plane) * p.Npad + n0 + n) * 8 + toff);
     }
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP p) {
     __bf16* dst = sW + buf * (TOTW * 8);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      *reinterpret_cast<u32x4*>(dst + (tid + j * 256) * 8) = rw[j];
+      *reinterpret_cast<u32x4*>(dst + (tid + j * NT) * 8) = rw[j];
     }
   };
 
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP p) {
   const __bf16* gw[NW];
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
-    const int u = tid + j * 256;
+    const int u = tid + j * NT;
     const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
     gw[j] = static_cast<const __bf16*>(p.w) + ((size_t)(k8l * 2 + plane) * p.Npad + n0 + n) * 8;
   }
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP p) {
     const size_t toff = ((size_t)tap * K8 + (size_t)chunk * 4) * wrow;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      __bf16* l = sW + buf * (TOTW * 8) + (wave * 64 + j * 256) * 8;   // wave-uniform base; the hardware adds lane*16 B
+      __bf16* l = sW + buf * (TOTW * 8) + (wave * 64 + j * NT) * 8;   // wave-uniform base; the hardware adds lane*16 B
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[j] + toff),
                                        (__attribute__((address_space(3))) void*)l, 16, 0, 0);
     }
@@ -297,10 +298,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail prefetches before the workgroup retires
   }
 
-  conv_epilogue<TH, TW, BN, FM, FN>(p, acc, b, oy0, ox0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem_raw));
+  conv_epilogue<TH, TW, BN, FM, FN, NWM>(p, acc, b, oy0, ox0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem_raw));
 }
 
-template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO>
+template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM = 2>
 static int launch3_cfg(ConvP& p, hipStream_t stream) {
   constexpr int THIN = (TH - 1) * STRIDE + KS, TWIN = (TW - 1) * STRIDE + KS;
   constexpr int NABUF = (KS == 1) ? 2 : 1;
@@ -310,14 +311,14 @@ static int launch3_cfg(ConvP& p, hipStream_t stream) {
   p.tiles_x = cdiv(p.Wout, TW);
   p.tiles_y = cdiv(p.Hout, TH);
   p.nt = cdiv(p.Npad, BN);
-  auto kern = conv_bf3_kernel<KS, STRIDE, UPS, TH, TW, BN, PRO>;
+  auto kern = conv_bf3_kernel<KS, STRIDE, UPS, TH, TW, BN, PRO, NWM>;
   static bool attr_done = false;
   if (!attr_done) {
     PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   const int grid = p.B * p.tiles_y * p.tiles_x * p.nt;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWM * 128), lds, stream, p);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }
@@ -331,6 +332,7 @@ static int dispatch_tile3(ConvP& p, int tile, hipStream_t s) {
   } else if constexpr (STRIDE == 2) {
     return launch3_cfg<3, 2, false, 4, 16, 64, PRO>(p, s);
   } else {
+    if (tile == 3) return launch3_cfg<3, 1, UPS, 16, 16, 64, PRO, 4>(p, s);
     if (tile == 0) return launch3_cfg<3, 1, UPS, 8, 16, 128, PRO>(p, s);
     if (tile == 1) return launch3_cfg<3, 1, UPS, 8, 16, 64, PRO>(p, s);
     return launch3_cfg<3, 1, UPS, 4, 16, 64, PRO>(p, s);

@@ -19,16 +19,29 @@ struct ConvP {
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
-__device__ __forceinline__ float gelu_erf_f(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f)); }
+// exact-erf GELU (F.gelu default, unet_attention.py:333).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, the size
+// of an fp32 ulp of erf near 1): one v_exp + one v_rcp + a degree-5 Horner chain instead of the ~50-instruction libm erff,
+// which dominated the GeGLU epilogue (64 evaluations per lane per tile).
+__device__ __forceinline__ float erf_as_f(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float pq = fmaf(1.061405429f, t, -1.453152027f);
+  pq = fmaf(pq, t, 1.421413741f);
+  pq = fmaf(pq, t, -0.284496736f);
+  pq = fmaf(pq, t, 0.254829592f);
+  const float y = 1.0f - pq * t * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_erf_f(float g) { return 0.5f * g * (1.0f + erf_as_f(g * 0.70710678118654752440f)); }
 
 // out[m][n] = acc + bias[n] + sbias[b][n] + res[m][n]   (or the GeGLU product), NHWC store.
 // When p.stats is set, the workgroup also emits the per-channel sum / sum-of-squares of what it stored, so that the
 // GroupNorm that consumes this tensor needs no pass over it (deterministic: lane pair -> LDS -> one writer per channel).
-// `red` is LDS scratch of at least 4*BN floats that no wave is still reading (callers barrier before reuse).
-template <int TH, int TW, int BN, int FM, int FN>
+// `red` is LDS scratch of at least 2*NWM*BN floats that no wave is still reading (callers barrier before reuse).
+template <int TH, int TW, int BN, int FM, int FN, int NWM = 2>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][FN], int b, int oy0, int ox0, int n0,
                                               int wm, int wn, int lane, int tid, float* red) {
-  constexpr int WM = TH * TW / 2, WN = BN / 2;
+  constexpr int WM = TH * TW / NWM, WN = BN / 2;
   const float* sb = p.sbias ? p.sbias + (size_t)b * p.ld_sbias : nullptr;
   const bool full = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (n0 + BN <= p.N) && !p.geglu;
   float ssum[FN], ssq[FN];
@@ -115,8 +128,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
     if (tid < BN && n0 + tid < p.N) {
       const int tile = (oy0 / TH) * p.tiles_x + ox0 / TW;
       float* dst = p.stats + (((size_t)b * (p.tiles_x * p.tiles_y) + tile) * p.N + n0 + tid) * 2;
-      dst[0] = red[tid * 2 + 0] + red[(BN + tid) * 2 + 0];
-      dst[1] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NWM; ++i) { a0 += red[(i * BN + tid) * 2 + 0]; a1 += red[(i * BN + tid) * 2 + 1]; }
+      dst[0] = a0; dst[1] = a1;
     }
   }
 }

@@ -19,6 +19,7 @@
 //   Arithmetic is v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain; the 1e-3 parity bar rules out
 //   bf16 inputs - SURVEY.md 0).  Both LDS images are double buffered and the next tile's global
 //   loads are in flight (registers) while the current tile's MFMAs run; one barrier per tile.
+#include <stdlib.h>
 #include "conv_common.h"
 
 namespace pf {
@@ -242,6 +243,11 @@ int conv_pick_tile(const pf_conv_args& a) {
   const int npad = (a.n + 63) / 64 * 64;
   const int mt128 = a.ks == 1 ? a.batch * hout * cdiv(wout, 128) : a.batch * cdiv(hout, 8) * cdiv(wout, 16);
   if (a.ks == 3 && a.stride == 2) return 2;
+  {  // bf16x3 3x3: 16x16-pixel tiles with 8 waves halve the weight bytes fetched per MFMA (the L2->CU pipe is the bound)
+    static const int force = getenv("PF_TILE") ? atoi(getenv("PF_TILE")) : -1;
+    if (force >= 0 && !(force == 3 && (a.precision != PF_PREC_BF16X3 || a.ks != 3))) return force;
+    if (a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.batch * cdiv(hout, 16) * cdiv(wout, 16) * (npad / 64) >= 256) return 3;
+  }
   if (npad % 128 == 0 && mt128 * (npad / 128) >= 512) return 0;
   if (mt128 * (npad / 64) >= 512) return 1;
   return 2;
@@ -249,7 +255,7 @@ int conv_pick_tile(const pf_conv_args& a) {
 void conv_tile_shape(const pf_conv_args& a, int tile, int* th, int* tw) {
   if (a.ks == 1) { *th = 1; *tw = tile == 2 ? 64 : 128; }
   else if (a.stride == 2) { *th = 4; *tw = 16; }
-  else { *th = tile == 2 ? 4 : 8; *tw = 16; }
+  else { *th = tile == 2 ? 4 : (tile == 3 ? 16 : 8); *tw = 16; }
 }
 int conv_stats_tiles(const pf_conv_args& a) {
   int hout, wout, th, tw;

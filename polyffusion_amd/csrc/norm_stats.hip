@@ -57,34 +57,33 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 }
 
 // scale/shift per (sample, channel) from per-tile (sum, sumsq) of one or two channel-concatenated producers.
-// fp64 accumulation over tiles and over the channels of a group; deterministic.
-__global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __restrict__ s0, int t0, int c0,
-                                                                const float* __restrict__ s1, int t1, int c1, int hw, int groups,
-                                                                float eps, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, float* __restrict__ scale,
-                                                                float* __restrict__ shift) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+// One 64-thread workgroup per (sample, group): the tile x channel partials of the group are summed in fp64
+// (lanes stride the (tile, channel) pairs, then a shuffle tree) - deterministic, no pass over the tensor.
+__global__ __launch_bounds__(64) void gn_finalize_tiles_kernel(const float* __restrict__ s0, int t0, int c0,
+                                                               const float* __restrict__ s1, int t1, int c1, int hw, int groups,
+                                                               float eps, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ scale,
+                                                               float* __restrict__ shift) {
+  const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const int C = c0 + c1;
-  const int tpg = 256 / groups;  // threads per group (power of two, <= 64)
-  const int g = tid / tpg, j = tid % tpg;
   const int gs = C / groups;
   double a = 0.0, q = 0.0;
   for (int ci = 0; ci < gs; ++ci) {
     const int c = g * gs + ci;
     const float* src; int T, cs, cl;
     if (c < c0) { src = s0; T = t0; cs = c0; cl = c; } else { src = s1; T = t1; cs = c1; cl = c - c0; }
-    for (int t = j; t < T; t += tpg) {
+    for (int t = lane; t < T; t += 64) {
       const float2 v = *reinterpret_cast<const float2*>(src + (((size_t)b * T + t) * cs + cl) * 2);
       a += v.x; q += v.y;
     }
   }
-  for (int off = tpg >> 1; off > 0; off >>= 1) { a += __shfl_xor(a, off); q += __shfl_xor(q, off); }
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); q += __shfl_xor(q, off); }
   const double cnt = (double)gs * hw;
   const double mean = a / cnt;
   double var = q / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
   const double rstd = 1.0 / sqrt(var + (double)eps);
-  for (int i = j; i < gs; i += tpg) {
+  for (int i = lane; i < gs; i += 64) {
     const int c = g * gs + i;
     const double ga = gamma[c];
     scale[(size_t)b * C + c] = (float)(rstd * ga);
@@ -96,9 +95,9 @@ int launch_gn_finalize_tiles(const float* s0, int t0, int c0, const float* s1, i
                              float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t stream) {
   const int C = c0 + c1;
   PF_REQUIRE(s0 && t0 > 0 && c0 > 0 && (c1 == 0 || (s1 && t1 > 0)), "gn_finalize: bad statistics inputs");
-  PF_REQUIRE(groups > 0 && 256 % groups == 0 && groups >= 4 && C % groups == 0, "gn: groups=%d unsupported for C=%d", groups, C);
-  hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(batch), dim3(256), 0, stream, s0, t0, c0, s1, t1, c1, hw, groups, eps, gamma,
-                     beta, scale, shift);
+  PF_REQUIRE(groups > 0 && C % groups == 0, "gn: groups=%d unsupported for C=%d", groups, C);
+  hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(groups, batch), dim3(64), 0, stream, s0, t0, c0, s1, t1, c1, hw, groups, eps,
+                     gamma, beta, scale, shift);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }

@@ -399,6 +399,9 @@ struct Ctx {
   // launch a conv/linear; when `stats` is given, the producer also emits per-tile channel statistics for a later GroupNorm
   // (buffer from the persistent or the temp region, matching the lifetime of the output tensor)
   void conv(pf_conv_args a, int kind, Tn* stats = nullptr, bool persist = true) {
+    const int cin_ = a.c0 + a.c1;
+    const bool bf3 = u->precision == PF_PREC_BF16X3 && cin_ % 32 == 0;
+    if (bf3) a.precision = PF_PREC_BF16X3;   // decided before the tile (and thus the statistics layout) is chosen
     if (stats) {
       const int nt = conv_stats_tiles(a);
       float* sb = persist ? palloc((size_t)B * nt * a.n * 2) : talloc((size_t)B * nt * a.n * 2);
@@ -407,11 +410,7 @@ struct Ctx {
     }
     prof_begin(kind, conv_flops(a));
     if (!dry && rc == PF_OK) {
-      const int cin = a.c0 + a.c1;
-      if (u->precision == PF_PREC_BF16X3 && cin % 32 == 0) {  // second half of the weight region = bf16x3 packing
-        a.precision = PF_PREC_BF16X3;
-        a.w = a.w + (size_t)a.ks * a.ks * cin * ((a.n + 63) / 64 * 64);
-      }
+      if (bf3) a.w = a.w + (size_t)a.ks * a.ks * cin_ * ((a.n + 63) / 64 * 64);  // second half of the region = bf16x3 packing
       rc = launch_conv(a, s);
     }
     prof_end();

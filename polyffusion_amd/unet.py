@@ -49,7 +49,7 @@ class UNetModel:
         self._blob_host: Optional[torch.Tensor] = None
         self._blob_dev: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
-        self._ws_key: Tuple[int, int] = (0, 0)
+        self._ws_key = (0, 0, 0)
 
     def __del__(self):
         try:
@@ -110,12 +110,13 @@ class UNetModel:
 
     # ---- forward --------------------------------------------------------------------------------
     def workspace(self, batch: int, n_cond: int) -> torch.Tensor:
-        if self._ws is None or self._ws_key != (batch, n_cond):
+        key = (batch, n_cond, self._lib.pf_unet_get_precision(self._h))  # tile choice (and buffer sizes) depend on the mode
+        if self._ws is None or self._ws_key != key:
             nbytes = self._lib.pf_unet_workspace_bytes(self._h, batch, n_cond)
             if self._ws is None or self._ws.numel() < nbytes:
                 self._ws = None
                 self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            self._ws_key = (batch, n_cond)
+            self._ws_key = key
         return self._ws
 
     def forward(self, x: torch.Tensor, time_steps: torch.Tensor, cond: torch.Tensor, out: Optional[torch.Tensor] = None):

@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Micro-benchmark of pf_conv2d on the UNet's layer shapes (B=16): time per launch and effective TFLOP/s.
+usage: python tools/bench_conv.py [f32|bf16x3] [filter]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from polyffusion_amd import _lib  # noqa: E402
+
+# name, B, H, W, c0, c1, cout, ks, stride, ups, prologue
+SHAPES = [
+    ("r128_64_64", 16, 128, 128, 64, 0, 64, 3, 1, 0, 1),
+    ("r128_128+64_64", 16, 128, 128, 128, 64, 64, 3, 1, 0, 1),
+    ("r64_128_128", 16, 64, 64, 128, 0, 128, 3, 1, 0, 1),
+    ("r64_256+128_128", 16, 64, 64, 256, 128, 128, 3, 1, 0, 1),
+    ("r32_256_256", 16, 32, 32, 256, 0, 256, 3, 1, 0, 1),
+    ("r32_256+256_256", 16, 32, 32, 256, 256, 256, 3, 1, 0, 1),
+    ("r16_256_256", 16, 16, 16, 256, 0, 256, 3, 1, 0, 1),
+    ("r16_256+256_256", 16, 16, 16, 256, 256, 256, 3, 1, 0, 1),
+    ("up64_128", 16, 64, 64, 128, 0, 128, 3, 1, 1, 0),
+    ("down128_64", 16, 128, 128, 64, 0, 64, 3, 2, 0, 0),
+    ("g1024_256_256", 16, 1, 1024, 256, 0, 256, 1, 1, 0, 0),
+    ("g1024_256_768ln", 16, 1, 1024, 256, 0, 768, 1, 1, 0, 3),
+    ("g1024_1024_256", 16, 1, 1024, 1024, 0, 256, 1, 1, 0, 0),
+    ("g256_256_256", 16, 1, 256, 256, 0, 256, 1, 1, 0, 0),
+    ("skip128_192_64", 16, 1, 16384, 128, 64, 64, 1, 1, 0, 0),
+]
+
+
+def main():
+    prec = 1 if (len(sys.argv) < 2 or sys.argv[1] == "bf16x3") else 0
+    flt = sys.argv[2] if len(sys.argv) > 2 else ""
+    lib = _lib.load()
+    for name, B, H, W, c0, c1, n, ks, stride, ups, pro in SHAPES:
+        if flt and flt not in name:
+            continue
+        cin = c0 + c1
+        x0 = torch.randn(B, H, W, c0, device="cuda")
+        x1 = torch.randn(B, H, W, c1, device="cuda") if c1 else None
+        taps = ks * ks
+        w = torch.randn(lib.pf_packed_gemm_weight_floats(n, cin, taps), device="cuda") * 0.01
+        ho, wo = (H * 2, W * 2) if ups else ((H // 2, W // 2) if stride == 2 else (H, W))
+        out = torch.empty(B, ho, wo, n, device="cuda")
+        sc = torch.ones(B, cin, device="cuda"); sh = torch.zeros(B, cin, device="cuda")
+        mean = torch.zeros(B * H * W, device="cuda"); rstd = torch.ones(B * H * W, device="cuda")
+        bias = torch.zeros(n, device="cuda")
+        res = torch.randn(B, ho, wo, n, device="cuda")
+        a = _lib.ConvArgs()
+        a.x0, a.c0, a.x1, a.c1 = x0.data_ptr(), c0, (x1.data_ptr() if c1 else 0), c1
+        a.batch, a.hin, a.win, a.ks, a.stride, a.ups = B, H, W, ks, stride, ups
+        a.w, a.n, a.prologue = w.data_ptr(), n, pro
+        a.sc, a.sh, a.mean, a.rstd = sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        a.bias, a.res, a.ld_res = bias.data_ptr(), res.data_ptr(), n
+        a.out, a.ld_out, a.precision = out.data_ptr(), n, prec
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            _lib.check(lib.pf_conv2d(C.byref(a), st))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 20
+        e0.record()
+        for _ in range(iters):
+            lib.pf_conv2d(C.byref(a), st)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        gf = 2.0 * B * ho * wo * n * cin * taps / 1e9
+        print(f"{name:18s} {us:8.1f} us  {gf:7.2f} GF  {gf / us * 1e3:7.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
