@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["conv_mfma.hip", "conv_bf16x3.hip", "attention.hip", "norm_stats.hip", "small_kernels.hip", "encoders.hip", "unet.hip"]
 LIB = os.path.join(HERE, "libpfhip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + (["-DPF_TRACE"] if os.environ.get("PF_TRACE") else [])
 
 
 def _stale(target: str, deps) -> bool:

@@ -22,12 +22,19 @@
 
 namespace pf {
 
+#ifdef PF_TRACE
+__device__ unsigned long long g_trace[8192];
+#define TR() do { if (trace_on && tslot < 2040) { g_trace[tbase + tslot++] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define TR() do {} while (0)
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM>
-__global__ __launch_bounds__(NWM * 128, NWM) void conv_bf3_kernel(ConvP p) {
+__global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   constexpr int NT = NWM * 128;            // threads: NWM x 2 waves
   constexpr int BK = 32;
   constexpr int BM = TH * TW;
@@ -56,6 +63,12 @@ __global__ __launch_bounds__(NWM * 128, NWM) void conv_bf3_kernel(ConvP p) {
   __bf16* sW = sAl + APLANE;               // [WRING bufs][4 k8][2 planes][BN][8]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef PF_TRACE
+  const bool trace_on = (tid == 0) && (blockIdx.x == 0 || blockIdx.x == 301 || blockIdx.x == gridDim.x - 1);
+  const int tbase = blockIdx.x == 0 ? 0 : (blockIdx.x == 301 ? 2048 : 4096);
+  int tslot = 0;
+  TR();
+#endif
   const int wm = wave >> 1, wn = wave & 1;
 
   const int nwg = gridDim.x;
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(NWM * 128, NWM) void conv_bf3_kernel(ConvP p) {
     if (cg < p.c0) { src = p.x0; cs = p.c0; co = cg; } else { src = p.x1; cs = p.c1; co = cg - p.c0; }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      if (poff[i] >= 0) ra[i] = *reinterpret_cast<const f32x4*>(src + (size_t)poff[i] * cs + co + c4 * 4);
+      if (poff[i] >= 0) ra[i] = *reinterpret_cast<const f32x4*>(src + co + (unsigned)(poff[i] * cs + c4 * 4));
       else ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (PRO == 1 || PRO == 2) {
@@ -116,28 +129,40 @@ __global__ __launch_bounds__(NWM * 128, NWM) void conv_bf3_kernel(ConvP p) {
       vsh = *reinterpret_cast<const f32x4*>(p.sh + cg + c4 * 4);
     }
   };
-  auto storeA = [&](int buf) {
+  // staged halo values after the prologue transform, split into bf16 hi / lo quads (kept in registers between the
+  // transform, which is scheduled in the shadow of a mid-chunk tap's MFMAs, and the LDS write at the chunk boundary)
+  bf16x4 qh[NA], ql[NA];
+  auto transformPiece = [&](int i) {
+    {
+      f32x4 v = ra[i];
+      if (PRO != 0 && poff[i] >= 0) {
+        if (PRO == 3) {
+          v = (v - pmu[i]) * prs[i] * vsc + vsh;
+        } else {
+          v = v * vsc + vsh;
+          if (PRO == 1) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+        }
+      }
+      qh[i] = __builtin_convertvector(v, bf16x4);
+      const f32x4 hf = __builtin_convertvector(qh[i], f32x4);
+      ql[i] = __builtin_convertvector(v - hf, bf16x4);
+    }
+  };
+  auto transformA = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) transformPiece(i);
+  };
+  auto writeA = [&](int buf) {
     const int base = buf * (NPIX * PITCH) + (tid / KQ) * PITCH + c4 * 4;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       if (tid / KQ + i * PSTEP < NPIX) {
-        f32x4 v = ra[i];
-        if (PRO != 0 && poff[i] >= 0) {
-          if (PRO == 3) {
-            v = (v - pmu[i]) * prs[i] * vsc + vsh;
-          } else {
-            v = v * vsc + vsh;
-            if (PRO == 1) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
-          }
-        }
-        const bf16x4 h = __builtin_convertvector(v, bf16x4);
-        const f32x4 hf = __builtin_convertvector(h, f32x4);
-        const bf16x4 l = __builtin_convertvector(v - hf, bf16x4);
-        *reinterpret_cast<bf16x4*>(sAh + base + i * PSTEP * PITCH) = h;
-        *reinterpret_cast<bf16x4*>(sAl + base + i * PSTEP * PITCH) = l;
+        *reinterpret_cast<bf16x4*>(sAh + base + i * PSTEP * PITCH) = qh[i];
+        *reinterpret_cast<bf16x4*>(sAl + base + i * PSTEP * PITCH) = ql[i];
       }
     }
   };
+  auto storeA = [&](int buf) { transformA(); writeA(buf); };
   auto loadW = [&](int chunk, int tap) {
     const size_t toff = ((size_t)tap * K8 + (size_t)chunk * 4) * ((size_t)2 * p.Npad * 8);
 #pragma unroll
@@ -240,65 +265,82 @@ __global__ __launch_bounds__(NWM * 128, NWM) void conv_bf3_kernel(ConvP p) {
     // through a WRING-deep LDS ring by direct global->LDS loads issued D = WRING-1 tiles ahead.  Waits are counted:
     // a thread's vmcnt only drains down to the (D-1) newest tiles, so D-1 tiles stay in flight across every barrier.
     constexpr int D = WRING - 1;
+    constexpr int NS = BK / 16;
     const int ntile = nchunk * TAPS;
 #pragma unroll
     for (int d = 0; d < D; ++d) { const int t = min(d, ntile - 1); gldsW(t / TAPS, t % TAPS, d); }
+    TR();
     loadA(0);
+    TR();
     storeA(0);
+    TR();
     int it = 0;
     for (int chunk = 0; chunk < nchunk; ++chunk) {
 #pragma unroll
       for (int tap = 0; tap < TAPS; ++tap, ++it) {
         // tile `it` is complete once at most (D-1)*NW of this thread's newer loads are outstanding (any extra ordinary
         // loads issued since only make the wait stricter); the barrier then publishes every wave's part and also
-        // guarantees that every wave has finished reading tile it-1, whose buffer is refilled right after it.
+        // guarantees that every wave has finished reading tile it-1, whose buffer is refilled during this tap.
+        TR();
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * NW) : "memory");
+        TR();
         __builtin_amdgcn_s_barrier();
-        {
-          const int t = min(it + D, ntile - 1);
-          gldsW(t / TAPS, t % TAPS, (it + D) % WRING);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (tap == 0 && chunk + 1 < nchunk) loadA(chunk + 1);
+        TR();
         const int aoff = ((tap / KS) * TWIN + (tap % KS)) * PITCH;
         const __bf16* cW = sW + (it % WRING) * (TOTW * 8) + wbase;
 #pragma unroll
-      for (int s = 0; s < BK / 16; ++s) {
-        bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+        for (int s2 = 0; s2 < NS; ++s2) {
+          bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm) {
-          ah[fm] = *reinterpret_cast<const bf16x8*>(sAh + aoff + hbase[fm] + s * 16);
-          al[fm] = *reinterpret_cast<const bf16x8*>(sAl + aoff + hbase[fm] + s * 16);
+          for (int fm = 0; fm < FM; ++fm) {
+            ah[fm] = *reinterpret_cast<const bf16x8*>(sAh + aoff + hbase[fm] + s2 * 16);
+            al[fm] = *reinterpret_cast<const bf16x8*>(sAl + aoff + hbase[fm] + s2 * 16);
+          }
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn) {
+            bh[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s2) * BN + fn * 32) * 8);
+            bl[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s2 + 1) * BN + fn * 32) * 8);
+          }
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
+          if (s2 == 0) {
+            // ... and the memory-side work is issued in the shadow of the MFMAs: the next ring slot's direct-to-LDS loads,
+            // the next chunk's halo loads (tap 0) and its normalise/activate/split arithmetic (tap 4)
+            const int t = min(it + D, ntile - 1);
+            gldsW(t / TAPS, t % TAPS, (it + D) % WRING);
+            if (tap == 0 && chunk + 1 < nchunk) loadA(chunk + 1);
+            if (chunk + 1 < nchunk) {   // pieces of the transform spread over taps 2..7, each hidden behind that tap's MFMAs
+#pragma unroll
+              for (int i = 0; i < NA; ++i)
+                if (tap == 2 + (i * 6) / NA) transformPiece(i);
+            }
+          }
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
         }
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) {
-          bh[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s) * BN + fn * 32) * 8);
-          bl[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s + 1) * BN + fn * 32) * 8);
-        }
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
-      }
+        asm volatile("s_nop 0" ::: "memory");
+        TR();
         if (tap == TAPS - 1 && chunk + 1 < nchunk) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();   // every wave has finished reading this chunk's halo
-          storeA(0);                      // visible to all after the next iteration's barrier (lgkmcnt(0) precedes it)
+          writeA(0);                      // visible to all after the next iteration's barrier (lgkmcnt(0) precedes it)
         }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail prefetches before the workgroup retires
   }
 
+  TR();
   conv_epilogue<TH, TW, BN, FM, FN, NWM>(p, acc, b, oy0, ox0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem_raw));
+  TR();
 }
 
 template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM = 2>
@@ -363,6 +405,16 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   if (a.ups) return dispatch_tile3<3, 1, true, 0>(p, tile, stream);
   return dispatch_tile3<3, 1, false, 1>(p, tile, stream);
 }
+
+#ifdef PF_TRACE
+extern "C" int pf_debug_trace_read(unsigned long long* dst, int n) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+extern "C" int pf_debug_trace_clear() {
+  static unsigned long long z[8192];
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // host: fp32 torch weight [N][K][taps] -> bf16x3 packing [tap][K/8][plane][Npad][8] at column col(n)
 static inline unsigned short f2bf_rne(float f) {

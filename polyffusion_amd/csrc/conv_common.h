@@ -18,7 +18,8 @@ struct ConvP {
   int tiles_x, tiles_y, nt;
 };
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division sequence (10 instructions shorter)
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 // exact-erf GELU (F.gelu default, unet_attention.py:333).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, the size
 // of an fp32 ulp of erf near 1): one v_exp + one v_rcp + a degree-5 Horner chain instead of the ~50-instruction libm erff,
 // which dominated the GeGLU epilogue (64 evaluations per lane per tile).
@@ -58,6 +59,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
       ncol[fn] = n0 + wn * WN + fn * 32 + (lane & 31);
       cb[fn] = (p.bias ? p.bias[ncol[fn]] : 0.f) + (sb ? sb[ncol[fn]] : 0.f);
     }
+    // phase 1: all residual loads back to back (out may alias nothing here, but the compiler cannot know: keeping the
+    // loads ahead of every store lets them pipeline instead of serialising load -> add -> store per element)
+    if (p.res) {
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int pp = wm * WM + fm * 32 + row;
+          const size_t m = mbase + (size_t)(pp / TW) * p.Wout + (pp % TW);
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn) acc[fm][fn][r] += p.res[m * p.ld_res + ncol[fn]];
+        }
+    }
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
 #pragma unroll
@@ -67,8 +82,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
         const size_t m = mbase + (size_t)(pp / TW) * p.Wout + (pp % TW);
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) {
-          float v = acc[fm][fn][r] + cb[fn];
-          if (p.res) v += p.res[m * p.ld_res + ncol[fn]];
+          const float v = acc[fm][fn][r] + cb[fn];
           p.out[m * p.ld_out + ncol[fn]] = v;
           ssum[fn] += v; ssq[fn] += v * v;
         }

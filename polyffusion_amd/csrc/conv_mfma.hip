@@ -246,7 +246,6 @@ int conv_pick_tile(const pf_conv_args& a) {
   {  // bf16x3 3x3: 16x16-pixel tiles with 8 waves halve the weight bytes fetched per MFMA (the L2->CU pipe is the bound)
     static const int force = getenv("PF_TILE") ? atoi(getenv("PF_TILE")) : -1;
     if (force >= 0 && !(force == 3 && (a.precision != PF_PREC_BF16X3 || a.ks != 3))) return force;
-    if (a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.batch * cdiv(hout, 16) * cdiv(wout, 16) * (npad / 64) >= 256) return 3;
   }
   if (npad % 128 == 0 && mt128 * (npad / 128) >= 512) return 0;
   if (mt128 * (npad / 64) >= 512) return 1;
