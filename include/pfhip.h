@@ -166,7 +166,10 @@ typedef struct pf_conv_args {
   float* out; int32_t ld_out;
   int32_t precision;                                         /* PF_PREC_F32 (w = fp32 packing) | PF_PREC_BF16X3 (w = bf16x3 packing) */
   float* stats_out;                                          /* optional [B][tiles][N][2] per-tile (sum, sumsq) of the outputs; see pf_conv_stats_tiles */
+  void* splitk_ws; size_t splitk_ws_bytes;                   /* optional scratch for split-K (small-M layers); see pf_conv_splitk_ws_bytes */
 } pf_conv_args;
+/* scratch bytes a launch with these arguments would like for split-K (0 = the launch does not split) */
+size_t pf_conv_splitk_ws_bytes(const pf_conv_args* a);
 /* number of per-sample tiles a pf_conv2d launch with these arguments emits into stats_out (0 on error) */
 int pf_conv_stats_tiles(const pf_conv_args* a);
 /* GroupNorm scale/shift from per-tile statistics of up to two channel-concatenated producers (no pass over the tensors) */

@@ -47,6 +47,7 @@ class ConvArgs(C.Structure):
         ("out", C.c_void_p), ("ld_out", C.c_int32),
         ("precision", C.c_int32),
         ("stats_out", C.c_void_p),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t),
     ]
 
 
@@ -91,6 +92,7 @@ SIGNATURES = {
     "pf_ln_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "pf_conv_stats_tiles": (C.c_int, [C.POINTER(ConvArgs)]),
+    "pf_conv_splitk_ws_bytes": (C.c_size_t, [C.POINTER(ConvArgs)]),
     "pf_gn_finalize_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

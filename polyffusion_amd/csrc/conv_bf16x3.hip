@@ -78,6 +78,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
+  const int sidx = lid % p.ksplit;   // K-slice (fastest varying: the slices of a tile run together and share its halo in L2)
+  lid /= p.ksplit;
   const int nti = lid % p.nt;
   int mt = lid / p.nt;
   const int tx = mt % p.tiles_x; mt /= p.tiles_x;
@@ -89,6 +91,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   const int Hlog = UPS ? 2 * p.Hin : p.Hin, Wlog = UPS ? 2 * p.Win : p.Win;
   const int cin = p.c0 + p.c1;
   const int K8 = cin / 8;
+  const int cbeg = (cin / BK) * sidx / p.ksplit;              // this workgroup's K-slice [cbeg, cbeg + nchunk) in BK-channel chunks
+  const int nchunk = (cin / BK) * (sidx + 1) / p.ksplit - cbeg;
 
   const int c4 = tid % KQ;
   int poff[NA];
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   vsc = f32x4{1.f, 1.f, 1.f, 1.f}; vsh = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto loadA = [&](int chunk) {
-    const int cg = chunk * BK;
+    const int cg = (cbeg + chunk) * BK;
     const float* src; int cs, co;
     if (cg < p.c0) { src = p.x0; cs = p.c0; co = cg; } else { src = p.x1; cs = p.c1; co = cg - p.c0; }
 #pragma unroll
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   };
   auto storeA = [&](int buf) { transformA(); writeA(buf); };
   auto loadW = [&](int chunk, int tap) {
-    const size_t toff = ((size_t)tap * K8 + (size_t)chunk * 4) * ((size_t)2 * p.Npad * 8);
+    const size_t toff = ((size_t)tap * K8 + (size_t)(cbeg + chunk) * 4) * ((size_t)2 * p.Npad * 8);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int u = tid + j * NT;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   }
   const size_t wrow = (size_t)2 * p.Npad * 8;   // bf16 elements per k8 row pair (hi|lo planes)
   auto gldsW = [&](int chunk, int tap, int buf) {
-    const size_t toff = ((size_t)tap * K8 + (size_t)chunk * 4) * wrow;
+    const size_t toff = ((size_t)tap * K8 + (size_t)(cbeg + chunk) * 4) * wrow;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       __bf16* l = sW + buf * (TOTW * 8) + (wave * 64 + j * NT) * 8;   // wave-uniform base; the hardware adds lane*16 B
@@ -217,7 +221,6 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[fm][fn][r] = 0.f;
 
-  const int nchunk = cin / BK;
 
   if constexpr (KS == 1) {
     // 1x1 / linear: A and W tiles both change every chunk; register-staged, double-buffered, one barrier per chunk
@@ -339,8 +342,46 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   }
 
   TR();
+  if (p.partial) p.partial += (size_t)sidx * ((size_t)p.B * p.Hout * p.Wout) * p.N;
   conv_epilogue<TH, TW, BN, FM, FN, NWM>(p, acc, b, oy0, ox0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem_raw));
   TR();
+}
+
+// out = sum_s partial[s] + bias + sbias[b] + res over a 64-row slab per workgroup; also emits the slab's per-channel
+// (sum, sumsq) as one statistics tile.  Deterministic (fixed summation order).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int M, int N, int hw,
+                                                            const float* __restrict__ bias, const float* __restrict__ sbias, int ld_sb,
+                                                            const float* __restrict__ res, int ld_res, float* __restrict__ out,
+                                                            int ld_out, float* __restrict__ stats) {
+  __shared__ float red[4][64][2];
+  const int tid = threadIdx.x, c = tid & 63, rg = tid >> 6;
+  const int row0 = blockIdx.x * 64;
+  const int b = row0 / hw, tile = (row0 % hw) / 64, ntiles = hw / 64;
+  {
+    const int n = blockIdx.y * 64 + c;
+    float s1 = 0.f, s2 = 0.f;
+    if (n < N) {
+      const float cb = (bias ? bias[n] : 0.f) + (sbias ? sbias[(size_t)b * ld_sb + n] : 0.f);
+      for (int i = 0; i < 16; ++i) {
+        const size_t m = row0 + rg + 4 * i;
+        float v = cb;
+        for (int s = 0; s < S; ++s) v += part[((size_t)s * M + m) * N + n];
+        if (res) v += res[m * ld_res + n];
+        out[m * ld_out + n] = v;
+        s1 += v; s2 += v * v;
+      }
+    }
+    if (stats) {
+      red[rg][c][0] = s1; red[rg][c][1] = s2;
+      __syncthreads();
+      if (rg == 0 && n < N) {
+        float* dst = stats + (((size_t)b * ntiles + tile) * N + n) * 2;
+        dst[0] = red[0][c][0] + red[1][c][0] + red[2][c][0] + red[3][c][0];
+        dst[1] = red[0][c][1] + red[1][c][1] + red[2][c][1] + red[3][c][1];
+      }
+      __syncthreads();
+    }
+  }
 }
 
 template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM = 2>
@@ -359,7 +400,7 @@ static int launch3_cfg(ConvP& p, hipStream_t stream) {
     PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  const int grid = p.B * p.tiles_y * p.tiles_x * p.nt;
+  const int grid = p.B * p.tiles_y * p.tiles_x * p.nt * p.ksplit;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NWM * 128), lds, stream, p);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
@@ -393,6 +434,8 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   p.sc = a.sc; p.sh = a.sh; p.mean = a.mean; p.rstd = a.rstd;
   p.bias = a.bias; p.sbias = a.sbias; p.ld_sbias = a.ld_sbias; p.res = a.res; p.ld_res = a.ld_res;
   p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out;
+  p.ksplit = conv_ksplit(a);
+  p.partial = p.ksplit > 1 ? static_cast<float*>(a.splitk_ws) : nullptr;
   const int tile = conv_pick_tile(a);
   if (a.ks == 1) {
     switch (a.prologue) {
@@ -402,8 +445,13 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
     }
   }
   if (a.stride == 2) return dispatch_tile3<3, 2, false, 0>(p, tile, stream);
-  if (a.ups) return dispatch_tile3<3, 1, true, 0>(p, tile, stream);
-  return dispatch_tile3<3, 1, false, 1>(p, tile, stream);
+  int rc = a.ups ? dispatch_tile3<3, 1, true, 0>(p, tile, stream) : dispatch_tile3<3, 1, false, 1>(p, tile, stream);
+  if (rc != PF_OK || p.ksplit == 1) return rc;
+  const int M = p.B * p.Hout * p.Wout;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M / 64, cdiv(p.N, 64)), dim3(256), 0, stream, static_cast<const float*>(a.splitk_ws), p.ksplit, M, p.N,
+                     p.Hout * p.Wout, p.bias, p.sbias, p.ld_sbias, p.res, p.ld_res, p.out, p.ld_out, p.stats);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
 }
 
 #ifdef PF_TRACE

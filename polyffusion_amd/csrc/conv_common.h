@@ -16,6 +16,7 @@ struct ConvP {
   float* out; int ld_out;
   float* stats;   // optional [B][tiles][N][2]: per-tile, per-channel (sum, sum of squares) of the stored outputs
   int tiles_x, tiles_y, nt;
+  int ksplit; float* partial;   // split-K: raw accumulators to partial[split][M][N]; bias/residual/statistics happen in the reduce kernel
 };
 
 // x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division sequence (10 instructions shorter)
@@ -43,6 +44,24 @@ template <int TH, int TW, int BN, int FM, int FN, int NWM = 2>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][FN], int b, int oy0, int ox0, int n0,
                                               int wm, int wn, int lane, int tid, float* red) {
   constexpr int WM = TH * TW / NWM, WN = BN / 2;
+  if (p.partial) {   // split-K slice: raw accumulators only
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int pp = wm * WM + fm * 32 + row;
+        const int oy = oy0 + pp / TW, ox = ox0 + pp % TW;
+        if (oy >= p.Hout || ox >= p.Wout) continue;
+        const size_t m = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+          const int n = n0 + wn * WN + fn * 32 + (lane & 31);
+          if (n < p.N) p.partial[m * p.N + n] = acc[fm][fn][r];
+        }
+      }
+    return;
+  }
   const float* sb = p.sbias ? p.sbias + (size_t)b * p.ld_sbias : nullptr;
   const bool full = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (n0 + BN <= p.N) && !p.geglu;
   float ssum[FN], ssq[FN];

@@ -256,9 +256,36 @@ void conv_tile_shape(const pf_conv_args& a, int tile, int* th, int* tw) {
   else if (a.stride == 2) { *th = 4; *tw = 16; }
   else { *th = tile == 2 ? 4 : (tile == 3 ? 16 : 8); *tw = 16; }
 }
+// split-K (bf16x3 3x3 only): layers whose tile grid cannot fill the chip (the 16x16 level at batch 16, most levels at
+// small batch) run ksplit K-slices per tile and a reduce kernel that also applies the epilogue
+static int ksplit_wanted(const pf_conv_args& a) {
+  if (a.precision != PF_PREC_BF16X3 || a.ks != 3 || a.stride != 1 || a.geglu) return 1;
+  int hout, wout, th, tw;
+  conv_out_dims(a, &hout, &wout);
+  if ((hout * wout) % 64 != 0) return 1;
+  conv_tile_shape(a, conv_pick_tile(a), &th, &tw);
+  const int blocks = a.batch * cdiv(hout, th) * cdiv(wout, tw) * cdiv((a.n + 63) / 64 * 64, 64);
+  const int nchunk = (a.c0 + a.c1) / 32;
+  if (blocks >= 512) return 1;
+  int s = 1;
+  while (s < 4 && blocks * s * 2 <= 1536 && nchunk % (s * 2) == 0) s *= 2;
+  return s;
+}
+size_t conv_splitk_ws_bytes(const pf_conv_args& a) {
+  const int s = ksplit_wanted(a);
+  if (s <= 1) return 0;
+  int hout, wout;
+  conv_out_dims(a, &hout, &wout);
+  return (size_t)s * a.batch * hout * wout * a.n * sizeof(float);
+}
+int conv_ksplit(const pf_conv_args& a) {
+  const size_t need = conv_splitk_ws_bytes(a);
+  return (need && a.splitk_ws && a.splitk_ws_bytes >= need) ? ksplit_wanted(a) : 1;
+}
 int conv_stats_tiles(const pf_conv_args& a) {
   int hout, wout, th, tw;
   conv_out_dims(a, &hout, &wout);
+  if (conv_ksplit(a) > 1) return hout * wout / 64;   // the reduce kernel emits one statistics tile per 64 rows
   conv_tile_shape(a, conv_pick_tile(a), &th, &tw);
   return cdiv(hout, th) * cdiv(wout, tw);
 }
@@ -319,6 +346,7 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
   p.sc = a.sc; p.sh = a.sh; p.mean = a.mean; p.rstd = a.rstd;
   p.bias = a.bias; p.sbias = a.sbias; p.ld_sbias = a.ld_sbias; p.res = a.res; p.ld_res = a.ld_res;
   p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out;
+  p.ksplit = 1; p.partial = nullptr;
 
   const int tile = conv_pick_tile(a);
 

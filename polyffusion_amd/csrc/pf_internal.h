@@ -34,7 +34,9 @@ double conv_flops(const pf_conv_args& a);
 int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream);  // called by launch_conv after validation
 int conv_pick_tile(const pf_conv_args& a);                        // 0: 128px x 128ch, 1: 128px x 64ch, 2: 64px x 64ch
 void conv_tile_shape(const pf_conv_args& a, int tile, int* th, int* tw);
-int conv_stats_tiles(const pf_conv_args& a);                      // per-sample tiles emitted into stats_out
+int conv_stats_tiles(const pf_conv_args& a);
+int conv_ksplit(const pf_conv_args& a);                           // K-split factor this launch uses (1 = none); needs a.splitk_ws
+size_t conv_splitk_ws_bytes(const pf_conv_args& a);              // scratch wanted for the split (0 = would not split)                      // per-sample tiles emitted into stats_out
 void pack_gemm_bf3(void* dst, const float* src, int n_src, int K, int taps, int Npad, int n_off, const int* colmap);
 
 int launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,

@@ -402,6 +402,10 @@ struct Ctx {
     const int cin_ = a.c0 + a.c1;
     const bool bf3 = u->precision == PF_PREC_BF16X3 && cin_ % 32 == 0;
     if (bf3) a.precision = PF_PREC_BF16X3;   // decided before the tile (and thus the statistics layout) is chosen
+    if (const size_t wsb = conv_splitk_ws_bytes(a)) {   // small-M layer: K-split partial sums live in the temp region
+      float* ws = talloc(wsb / 4);
+      a.splitk_ws = dry ? (void*)1 : (void*)ws; a.splitk_ws_bytes = wsb;
+    }
     if (stats) {
       const int nt = conv_stats_tiles(a);
       float* sb = persist ? palloc((size_t)B * nt * a.n * 2) : talloc((size_t)B * nt * a.n * 2);
@@ -827,6 +831,7 @@ int pf_ln_stats(const float* x, int rows, int c, float eps, float* mean, float* 
   return launch_ln_stats(x, rows, c, eps, mean, rstd, (hipStream_t)stream);
 }
 int pf_conv_stats_tiles(const pf_conv_args* a) { return a ? conv_stats_tiles(*a) : 0; }
+size_t pf_conv_splitk_ws_bytes(const pf_conv_args* a) { return a ? conv_splitk_ws_bytes(*a) : 0; }
 int pf_gn_finalize_tiles(const float* stats0, int tiles0, int c0, const float* stats1, int tiles1, int c1, int batch, int hw,
                          int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
   return launch_gn_finalize_tiles(stats0, tiles0, c0, stats1, tiles1, c1, batch, hw, groups, eps, gamma, beta, scale, shift,

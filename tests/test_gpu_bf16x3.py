@@ -131,3 +131,35 @@ def test_small_unet_bf16x3_vs_reference_golden(golden):
     x, t = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda()
     assert np.abs(m(x, t, torch.from_numpy(g["cond1"]).cuda()).cpu().numpy() - g["out1"]).max() < 5e-4
     assert np.abs(m(x, t, torch.from_numpy(g["cond4"]).cuda()).cpu().numpy() - g["out4"]).max() < 5e-4
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,cout", [(2, 16, 16, 256, 256, 256), (1, 8, 8, 64, 0, 64), (16, 16, 16, 256, 0, 256)])
+def test_split_k_small_m_layers(lib, B, H, W, c0, c1, cout):
+    """Small-M 3x3 layers split K over workgroups; the reduce kernel applies bias/sbias/residual and emits the statistics."""
+    cin = c0 + c1
+    x = rnd((B, cin, H, W), 1) * 1.5 + 0.3
+    w, bias = rnd((cout, cin, 3, 3), 2, (1.0 / (cin * 9)) ** 0.5), rnd((cout,), 3, 0.1)
+    gamma, beta = 1 + 0.1 * rnd((cin,), 4), 0.1 * rnd((cin,), 5)
+    sb, res = rnd((B, cout), 6), rnd((B, cout, H, W), 7)
+    ref = F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-5)), w, bias, padding=1) + sb[:, :, None, None] + res
+    x0 = dev(nhwc(x[:, :c0]))
+    x1 = dev(nhwc(x[:, c0:])) if c1 else None
+    sc, sh = gn_scale_shift(lib, x0, x1, dev(gamma), dev(beta), 1e-5)
+    kw = dict(x0=x0, c0=c0, x1=x1, c1=c1, batch=B, hin=H, win=W, ks=3, stride=1, ups=0, w=pack3(lib, w), n=cout,
+              prologue=1, sc=sc, sh=sh, bias=dev(bias), sbias=dev(sb), ld_sbias=cout, res=dev(nhwc(res)), ld_res=cout, precision=1)
+    a = _lib.ConvArgs()
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+    need = lib.pf_conv_splitk_ws_bytes(C.byref(a))
+    assert need > 0, "shape was expected to split"
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    a.splitk_ws, a.splitk_ws_bytes = ws.data_ptr(), need
+    nt = lib.pf_conv_stats_tiles(C.byref(a))
+    assert nt == H * W // 64
+    out = torch.empty(B, H, W, cout, device="cuda")
+    stats = torch.full((B, nt, cout, 2), float("nan"), device="cuda")
+    run_conv(lib, out=out, ld_out=cout, stats_out=stats, splitk_ws=ws, splitk_ws_bytes=need, **kw)
+    assert (out.cpu() - nhwc(ref)).abs().max() < TOL_OP
+    o = out.cpu().double()
+    tot = stats.cpu().double().sum(1)
+    assert (tot[..., 0] - o.sum((1, 2))).abs().max() < 1e-2 and (tot[..., 1] - (o * o).sum((1, 2))).abs().max() < 1e-2
