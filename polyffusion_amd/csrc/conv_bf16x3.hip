@@ -349,12 +349,12 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
 
 // out = sum_s partial[s] + bias + sbias[b] + res over a 64-row slab per workgroup; also emits the slab's per-channel
 // (sum, sumsq) as one statistics tile.  Deterministic (fixed summation order).
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int M, int N, int hw,
+__global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __restrict__ part, int S, int M, int N, int hw,
                                                             const float* __restrict__ bias, const float* __restrict__ sbias, int ld_sb,
                                                             const float* __restrict__ res, int ld_res, float* __restrict__ out,
                                                             int ld_out, float* __restrict__ stats) {
-  __shared__ float red[4][64][2];
-  const int tid = threadIdx.x, c = tid & 63, rg = tid >> 6;
+  __shared__ float red[16][64][2];
+  const int tid = threadIdx.x, c = tid & 63, rg = tid >> 6;   // 16 row groups x 64 columns
   const int row0 = blockIdx.x * 64;
   const int b = row0 / hw, tile = (row0 % hw) / 64, ntiles = hw / 64;
   {
@@ -362,8 +362,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     float s1 = 0.f, s2 = 0.f;
     if (n < N) {
       const float cb = (bias ? bias[n] : 0.f) + (sbias ? sbias[(size_t)b * ld_sb + n] : 0.f);
-      for (int i = 0; i < 16; ++i) {
-        const size_t m = row0 + rg + 4 * i;
+      for (int i = 0; i < 4; ++i) {
+        const size_t m = row0 + rg + 16 * i;
         float v = cb;
         for (int s = 0; s < S; ++s) v += part[((size_t)s * M + m) * N + n];
         if (res) v += res[m * ld_res + n];
@@ -376,8 +376,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       __syncthreads();
       if (rg == 0 && n < N) {
         float* dst = stats + (((size_t)b * ntiles + tile) * N + n) * 2;
-        dst[0] = red[0][c][0] + red[1][c][0] + red[2][c][0] + red[3][c][0];
-        dst[1] = red[0][c][1] + red[1][c][1] + red[2][c][1] + red[3][c][1];
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { a0 += red[j][c][0]; a1 += red[j][c][1]; }
+        dst[0] = a0; dst[1] = a1;
       }
       __syncthreads();
     }
@@ -448,7 +450,7 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   int rc = a.ups ? dispatch_tile3<3, 1, true, 0>(p, tile, stream) : dispatch_tile3<3, 1, false, 1>(p, tile, stream);
   if (rc != PF_OK || p.ksplit == 1) return rc;
   const int M = p.B * p.Hout * p.Wout;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M / 64, cdiv(p.N, 64)), dim3(256), 0, stream, static_cast<const float*>(a.splitk_ws), p.ksplit, M, p.N,
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M / 64, cdiv(p.N, 64)), dim3(1024), 0, stream, static_cast<const float*>(a.splitk_ws), p.ksplit, M, p.N,
                      p.Hout * p.Wout, p.bias, p.sbias, p.ld_sbias, p.res, p.ld_res, p.out, p.ld_out, p.stats);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;

@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""Cycle-stamp timeline of one workgroup of the bf16x3 1x1/linear kernel (needs a PF_TRACE build)."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from polyffusion_amd import _lib
+import tools.bench_conv as bc
+lib = _lib.load()
+name = sys.argv[1] if len(sys.argv) > 1 else "g1024_256_256"
+sys.argv = ["x", "bf16x3", name]
+lib.pf_debug_trace_clear()
+bc.main()
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * 8192)()
+lib.pf_debug_trace_read(buf, 8192)
+a = np.array(buf[:], dtype=np.int64)
+for base, tag in ((0, "block0"), (2048, "block301"), (4096, "blocklast")):
+    t = a[base:base + 2048]; t = t[t > 0]
+    if len(t) < 8: continue
+    d = np.diff(t)
+    print(tag, "n", len(t), "total cycles", t[-1] - t[0])
+    print("  prologue: setup", d[0], " load issue", d[1], " wait+transform+store", d[2])
+    body = d[3:-2]
+    n = len(body) // 4 * 4
+    b = body[:n].reshape(-1, 4)
+    print("  per chunk [barrier/top, load issue, lds+mfma, wait+transform+store]:")
+    for r in b[:10]: print("    ", r.tolist(), "sum", int(r.sum()))
+    print("  tail", d[-2:].tolist())
