@@ -438,6 +438,7 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out;
   p.ksplit = conv_ksplit(a);
   p.partial = p.ksplit > 1 ? static_cast<float*>(a.splitk_ws) : nullptr;
+  p.qkv = a.qkv_planes;
   const int tile = conv_pick_tile(a);
   if (a.ks == 1) {
     switch (a.prologue) {

@@ -16,6 +16,7 @@ struct ConvP {
   float* out; int ld_out;
   float* stats;   // optional [B][tiles][N][2]: per-tile, per-channel (sum, sum of squares) of the stored outputs
   int tiles_x, tiles_y, nt;
+  void* qkv;                    // fused q|k|v projection written as bf16 hi/lo planes for attention_bf3.hip (d_head 64)
   int ksplit; float* partial;   // split-K: raw accumulators to partial[split][M][N]; bias/residual/statistics happen in the reduce kernel
 };
 
@@ -60,6 +61,58 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
           if (n < p.N) p.partial[m * p.N + n] = acc[fm][fn][r];
         }
       }
+    return;
+  }
+  if (p.qkv) {
+    // q|k|v planes for the bf16x3 attention: Q,K [token][C] and V^T [head][d][token] (middle token quads of every
+    // 16-token block swapped, see attention_bf3.hip), each as a bf16 hi plane and a bf16 lo = bf16(x - hi) plane.
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    const int C = p.N / 3, L = p.Wout, H = C / 64;
+    const size_t MC = (size_t)p.B * L * C;
+    __bf16* base = static_cast<__bf16*>(p.qkv);
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+      const int n = n0 + wn * WN + fn * 32 + (lane & 31);
+      if (n >= p.N) continue;
+      const int which = n / C, cc = n - which * C;
+      const float bn = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) {
+        const int tok0 = ox0 + wm * WM + fm * 32;   // first token of this 32-row fragment (dense mode: TH == 1)
+        if (which < 2) {
+          __bf16* ph = base + (size_t)(2 * which) * MC + ((size_t)b * L + tok0) * C + cc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (tok0 + row >= L) continue;
+            const float v = acc[fm][fn][r] + bn;
+            const __bf16 hi = (__bf16)v;
+            ph[(size_t)row * C] = hi;
+            ph[MC + (size_t)row * C] = (__bf16)(v - (float)hi);
+          }
+        } else {
+          const int hh = cc / 64, d = cc % 64;
+          __bf16* pv = base + 4 * MC + (((size_t)b * H + hh) * 64 + d) * L;
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int t0 = tok0 + 8 * rq + 4 * (lane >> 5);   // four consecutive tokens held in registers 4rq..4rq+3
+            if (t0 >= L) continue;
+            const int qd = (t0 >> 2) & 3;
+            const int qp = (qd == 1) ? 2 : (qd == 2 ? 1 : qd);
+            bf16x4_t hi4, lo4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float v = acc[fm][fn][4 * rq + j] + bn;
+              hi4[j] = (__bf16)v;
+              lo4[j] = (__bf16)(v - (float)hi4[j]);
+            }
+            const size_t off = (size_t)(t0 & ~15) + qp * 4;
+            *reinterpret_cast<bf16x4_t*>(pv + off) = hi4;
+            *reinterpret_cast<bf16x4_t*>(pv + MC + off) = lo4;
+          }
+        }
+      }
+    }
     return;
   }
   const float* sb = p.sbias ? p.sbias + (size_t)b * p.ld_sbias : nullptr;

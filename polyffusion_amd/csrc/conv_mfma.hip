@@ -332,6 +332,8 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
   PF_REQUIRE(!(a.ks == 3 && a.prologue == 0 && !a.ups && a.stride == 1), "conv: plain 3x3 without prologue is not instantiated");
   PF_REQUIRE(!(a.ks == 1 && a.prologue == 1), "conv: 1x1 with SiLU prologue is not instantiated");
   PF_REQUIRE(!(a.stats_out && a.geglu), "conv: statistics are not available with the GeGLU epilogue");
+  PF_REQUIRE(!a.qkv_planes || (a.ks == 1 && a.n % 192 == 0 && a.win % 16 == 0 && !a.geglu && !a.res && !a.sbias && !a.stats_out),
+             "conv: qkv planes need ks=1, N = 3*heads*64 and L %% 16 == 0");
 
   PF_REQUIRE(a.precision == PF_PREC_F32 || a.precision == PF_PREC_BF16X3, "conv: bad precision %d", a.precision);
   if (a.precision == PF_PREC_BF16X3) return launch_conv_bf3(a, stream);
@@ -346,7 +348,7 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
   p.sc = a.sc; p.sh = a.sh; p.mean = a.mean; p.rstd = a.rstd;
   p.bias = a.bias; p.sbias = a.sbias; p.ld_sbias = a.ld_sbias; p.res = a.res; p.ld_res = a.ld_res;
   p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out;
-  p.ksplit = 1; p.partial = nullptr;
+  p.ksplit = 1; p.partial = nullptr; p.qkv = a.qkv_planes;
 
   const int tile = conv_pick_tile(a);
 

@@ -508,13 +508,18 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
     const Layer::TB& t = L.tbs[i];
     // x = attn1(LN1(x)) + x
     c.ln(t0, M, C, mu, rs);
+    // bf16x3 mode, d_head 64, L % 128 == 0: the projection writes pre-split q/k/v^T planes and attention runs on the bf16 pipe
+    const bool planes = c.u->precision == PF_PREC_BF16X3 && dh == 64 && hw % 128 == 0 && C % 32 == 0;
     {
       pf_conv_args a = conv_base(t0, C, nullptr, 0, B, 1, hw, 1, c.w(t.qkv), 3 * C, qkv);
       a.prologue = 3; a.sc = c.w(t.n1g); a.sh = c.w(t.n1b); a.mean = mu; a.rstd = rs;
+      if (planes) a.qkv_planes = c.dry ? (void*)1 : (void*)qkv;   // same bytes as the fp32 [M][3C] buffer
       c.conv(a, PF_K_GEMM);
     }
     c.prof_begin(PF_K_ATTN, 4.0 * B * nh * (double)hw * hw * dh);
-    if (!c.dry && c.rc == PF_OK) c.rc = launch_attention(qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, att, C, B, nh, dh, hw, hw, c.s);
+    if (!c.dry && c.rc == PF_OK)
+      c.rc = planes ? launch_attention_bf3(qkv, att, C, B, nh, hw, c.s)
+                    : launch_attention(qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, att, C, B, nh, dh, hw, hw, c.s);
     c.prof_end();
     {
       pf_conv_args a = conv_base(att, C, nullptr, 0, B, 1, hw, 1, c.w(t.o1w), C, t1);
@@ -840,6 +845,9 @@ int pf_gn_finalize_tiles(const float* stats0, int tiles0, int c0, const float* s
 int pf_conv2d(const pf_conv_args* a, void* stream) {
   PF_REQUIRE(a, "pf_conv2d: null argument");
   return launch_conv(*a, (hipStream_t)stream);
+}
+int pf_attention_bf16x3(const void* qkv_planes, float* o, int ldo, int batch, int n_heads, int l, void* stream) {
+  return launch_attention_bf3(qkv_planes, o, ldo, batch, n_heads, l, (hipStream_t)stream);
 }
 int pf_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int batch,
                  int n_heads, int d_head, int lq, int lk, void* stream) {

@@ -163,3 +163,32 @@ def test_split_k_small_m_layers(lib, B, H, W, c0, c1, cout):
     o = out.cpu().double()
     tot = stats.cpu().double().sum(1)
     assert (tot[..., 0] - o.sum((1, 2))).abs().max() < 1e-2 and (tot[..., 1] - (o * o).sum((1, 2))).abs().max() < 1e-2
+
+
+@pytest.mark.parametrize("B,L,H", [(2, 1024, 4), (3, 256, 4), (1, 128, 2)])
+def test_qkv_planes_and_bf16x3_attention(lib, B, L, H):
+    """q|k|v projection (LayerNorm prologue) written as pre-split bf16 hi/lo planes, consumed by the bf16x3 attention."""
+    c = H * 64
+    x = rnd((B, L, c), 81) * 1.3 + 0.2
+    gamma, beta = 1 + 0.1 * rnd((c,), 82), 0.1 * rnd((c,), 83)
+    w = rnd((3 * c, c), 84, c ** -0.5) * 1.5
+    qkv = F.linear(F.layer_norm(x, (c,), gamma, beta), w)
+    q, k, v = (t.reshape(B, L, H, 64) for t in qkv.chunk(3, dim=-1))
+    att = (torch.einsum("bihd,bjhd->bhij", q, k) * 0.125).softmax(-1)
+    ref = torch.einsum("bhij,bjhd->bihd", att, v).reshape(B, L, c)
+    xd = dev(x)
+    mu, rs = torch.empty(B * L, device="cuda"), torch.empty(B * L, device="cuda")
+    _lib.check(lib.pf_ln_stats(xd.data_ptr(), B * L, c, 1e-5, mu.data_ptr(), rs.data_ptr(), _lib.current_stream()))
+    planes = torch.zeros(B * L * 3 * c, dtype=torch.float32, device="cuda")   # 6 bf16 planes = the bytes of fp32 [M][3C]
+    dummy = torch.empty(1, device="cuda")
+    run_conv(lib, x0=xd, c0=c, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, w), n=3 * c, prologue=3,
+             sc=dev(gamma), sh=dev(beta), mean=mu, rstd=rs, out=dummy, ld_out=3 * c, precision=1, qkv_planes=planes)
+    # the planes reconstruct the projection: hi + lo == qkv to ~2^-17
+    pl = planes.view(torch.bfloat16).float().cpu().view(6, B, L * c)
+    qrec = (pl[0] + pl[1]).view(B, L, c)
+    assert (qrec - qkv[..., :c]).abs().max() < 3e-4
+    out = torch.empty(B, L, c, device="cuda")
+    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, B, H, L, _lib.current_stream()))
+    torch.cuda.synchronize()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 3e-4, err
