@@ -167,6 +167,8 @@ typedef struct pf_conv_args {
   int32_t precision;                                         /* PF_PREC_F32 (w = fp32 packing) | PF_PREC_BF16X3 (w = bf16x3 packing) */
   float* stats_out;                                          /* optional [B][tiles][N][2] per-tile (sum, sumsq) of the outputs; see pf_conv_stats_tiles */
   void* splitk_ws; size_t splitk_ws_bytes;                   /* optional scratch for split-K (small-M layers); see pf_conv_splitk_ws_bytes */
+  int32_t a_planes;                                          /* x0 is NOT fp32 but bf16 hi/lo planes [M][K] | [M][K] from a producer's out_planes (ks=1, prologue 0, bf16x3) */
+  void* out_planes;                                          /* optional: write the result as bf16 hi/lo planes [M][ld_out] | [M][ld_out] instead of fp32 `out` */
   void* qkv_planes;                                          /* optional (ks=1, N = 3C, d_head 64): instead of `out`, write the fused q|k|v projection
                                                                 as bf16 hi/lo planes [qh|ql|kh|kl|vTh|vTl] (each B*L*C) for pf_attention_bf16x3 */
 } pf_conv_args;
@@ -181,8 +183,9 @@ int pf_conv2d(const pf_conv_args* a, void* stream);
 
 /* softmax(q k^T * d_head^-0.5) v per (batch, head); q [B,Lq,*], k/v [B,Lk,*] with row strides ld*, heads packed
  * along the last dim (unet_attention.py:261-293). d_head in {32,64}. */
-/* self-attention on the pre-split planes written by pf_conv2d(qkv_planes=...): d_head 64, L %% 128 == 0 (bf16x3 split MFMA) */
-int pf_attention_bf16x3(const void* qkv_planes, float* o, int ldo, int batch, int n_heads, int l, void* stream);
+/* self-attention on the pre-split planes written by pf_conv2d(qkv_planes=...): d_head 64, L %% 128 == 0 (bf16x3 split MFMA);
+ * the result goes to fp32 `o` or, when o_planes != NULL, to bf16 hi/lo planes [M][C] | [M][C] for a following planes GEMM */
+int pf_attention_bf16x3(const void* qkv_planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, void* stream);
 int pf_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                  int batch, int n_heads, int d_head, int lq, int lk, void* stream);
 

@@ -48,6 +48,7 @@ class ConvArgs(C.Structure):
         ("precision", C.c_int32),
         ("stats_out", C.c_void_p),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t),
+        ("a_planes", C.c_int32), ("out_planes", C.c_void_p),
         ("qkv_planes", C.c_void_p),
     ]
 
@@ -96,7 +97,7 @@ SIGNATURES = {
     "pf_conv_splitk_ws_bytes": (C.c_size_t, [C.POINTER(ConvArgs)]),
     "pf_gn_finalize_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "pf_attention_bf16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pf_attention_bf16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pf_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }

@@ -21,7 +21,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct AttnP3 {
   const __bf16* planes;   // [qh | ql | kh | kl | vth | vtl], each B*L*C elements
-  float* o; int ldo;
+  float* o; int ldo; __bf16* o_planes;
   int B, H, L;
   float scale;
 };
@@ -161,13 +161,22 @@ __global__ __launch_bounds__(256, 2) void attn_bf3_kernel(AttnP3 p) {
       f32x4 v;
       v[0] = oacc[df][4 * c + 0] * inv; v[1] = oacc[df][4 * c + 1] * inv;
       v[2] = oacc[df][4 * c + 2] * inv; v[3] = oacc[df][4 * c + 3] * inv;
-      *reinterpret_cast<f32x4*>(op + df * 32 + 8 * c + 4 * g) = v;
+      if (p.o_planes) {   // hi/lo planes [M][C] for the to_out planes GEMM
+        bf16x4 h4 = __builtin_convertvector(v, bf16x4);
+        const f32x4 hf = __builtin_convertvector(h4, f32x4);
+        bf16x4 l4 = __builtin_convertvector(v - hf, bf16x4);
+        __bf16* pp = p.o_planes + ((size_t)b * L + qi) * C + h * DH + df * 32 + 8 * c + 4 * g;
+        *reinterpret_cast<bf16x4*>(pp) = h4;
+        *reinterpret_cast<bf16x4*>(pp + MC) = l4;
+      } else {
+        *reinterpret_cast<f32x4*>(op + df * 32 + 8 * c + 4 * g) = v;
+      }
     }
 }
 
-int launch_attention_bf3(const void* planes, float* o, int ldo, int batch, int n_heads, int l, hipStream_t stream) {
-  PF_REQUIRE(planes && o && batch > 0 && n_heads > 0 && l > 0 && l % 128 == 0, "attention_bf3: L must be a positive multiple of 128");
-  AttnP3 p{static_cast<const __bf16*>(planes), o, ldo, batch, n_heads, l, 0.125f};
+int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, hipStream_t stream) {
+  PF_REQUIRE(planes && (o || o_planes) && batch > 0 && n_heads > 0 && l > 0 && l % 128 == 0, "attention_bf3: L must be a positive multiple of 128");
+  AttnP3 p{static_cast<const __bf16*>(planes), o, ldo, static_cast<__bf16*>(o_planes), batch, n_heads, l, 0.125f};
   constexpr size_t lds = (size_t)2 * 4 * 64 * 64 * 2;
   static bool done = false;
   if (!done) { PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }

@@ -18,6 +18,8 @@
 //     consecutive-k B operands are one 16-byte LDS read per plane;
 //   * BK = 32; the 3x3 halo image is single-buffered (it changes every 9 taps; its global loads are
 //     issued three taps ahead), weight tiles are double-buffered; 1x1 mode double-buffers both.
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace pf {
@@ -32,6 +34,22 @@ __device__ unsigned long long g_trace[8192];
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// LDS fragment read issued as inline asm, NOT as a C++ load: with direct-to-LDS loads in flight the compiler's wait-count
+// pass degrades every LDS dependency to lgkmcnt(0) (a pending global_load_lds counts as a "flat" access), which serialises
+// each ds_read with its MFMA.  The 3x3 loop therefore issues its reads here and places counted s_waitcnt lgkmcnt(N) itself.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return __builtin_bit_cast(bf16x8, v);
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 
 template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM>
 __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
@@ -122,8 +140,9 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     if (cg < p.c0) { src = p.x0; cs = p.c0; co = cg; } else { src = p.x1; cs = p.c1; co = cg - p.c0; }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      if (poff[i] >= 0) ra[i] = *reinterpret_cast<const f32x4*>(src + co + (unsigned)(poff[i] * cs + c4 * 4));
-      else ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // unconditional (padding / out-of-tile pieces read pixel 0 and are zeroed by the transform): the number of
+      // vector loads in flight is then a compile-time constant, which the counted vmcnt waits of the 3x3 loop rely on
+      ra[i] = *reinterpret_cast<const f32x4*>(src + co + (unsigned)(max(poff[i], 0) * cs + c4 * 4));
     }
     if (PRO == 1 || PRO == 2) {
       vsc = *reinterpret_cast<const f32x4*>(p.sc + (size_t)b * cin + cg + c4 * 4);
@@ -139,7 +158,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   auto transformPiece = [&](int i) {
     {
       f32x4 v = ra[i];
-      if (PRO != 0 && poff[i] >= 0) {
+      if (poff[i] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      else if (PRO != 0) {
         if (PRO == 3) {
           v = (v - pmu[i]) * prs[i] * vsc + vsh;
         } else {
@@ -186,20 +206,15 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
 
   // direct global->LDS copy of one weight tile (no registers, no transform): LDS image = tile order, lane-linear
   // per-thread source pointers of the NW pieces inside a tile are fixed; a tile only adds a wave-uniform offset
-  const __bf16* gw[NW];
-#pragma unroll
-  for (int j = 0; j < NW; ++j) {
-    const int u = tid + j * NT;
-    const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
-    gw[j] = static_cast<const __bf16*>(p.w) + ((size_t)(k8l * 2 + plane) * p.Npad + n0 + n) * 8;
-  }
+  static_assert(NT % (2 * BN) == 0, "pieces of a thread must be whole k8 rows apart");
   const size_t wrow = (size_t)2 * p.Npad * 8;   // bf16 elements per k8 row pair (hi|lo planes)
+  const __bf16* gw0 = static_cast<const __bf16*>(p.w) + ((size_t)((tid / (2 * BN)) * 2 + ((tid / BN) & 1)) * p.Npad + n0 + tid % BN) * 8;
   auto gldsW = [&](int chunk, int tap, int buf) {
     const size_t toff = ((size_t)tap * K8 + (size_t)(cbeg + chunk) * 4) * wrow;
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       __bf16* l = sW + buf * (TOTW * 8) + (wave * 64 + j * NT) * 8;   // wave-uniform base; the hardware adds lane*16 B
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[j] + toff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw0 + toff + (size_t)j * (NT / (2 * BN)) * wrow),
                                        (__attribute__((address_space(3))) void*)l, 16, 0, 0);
     }
   };
@@ -265,80 +280,130 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     }
   } else {
     // 3x3: the halo image changes every 9 taps (register-staged, transformed, single buffer); weight tiles stream
-    // through a WRING-deep LDS ring by direct global->LDS loads issued D = WRING-1 tiles ahead.  Waits are counted:
-    // a thread's vmcnt only drains down to the (D-1) newest tiles, so D-1 tiles stay in flight across every barrier.
-    constexpr int D = WRING - 1;
+    // through a 3-slot LDS ring by direct global->LDS loads.  A 16-deep K step is three MFMA groups on one fragment set
+    //     X = a_lo x w_hi      Z = a_hi x w_hi      Y = a_hi x w_lo
+    // and every fragment is re-loaded for the NEXT step as soon as its last reader has issued (a_lo after X, w_hi after
+    // Z, a_hi / w_lo after Y), so each ds_read has one or two MFMA groups of cover and no second register set is needed:
+    //
+    //   tap it:   X0 | ld a_lo(1)     Z0 | ld w_hi(1)     Y0 | ld a_hi(1), w_lo(1)     X1
+    //             wait: tile it+1 landed, own LDS reads done; s_barrier
+    //             -> every read of ring slot it%3 has completed: refill it with tile it+3 (two tiles stay in flight)
+    //             ld a_lo(0')      Z1 | ld w_hi(0')     Y1 | ld a_hi(0'), w_lo(0')          (0' = step 0 of tap it+1)
+    //
+    // One barrier per tap.  At a chunk boundary the halo buffer is rewritten right after the barrier of tap 8 (every wave
+    // holds its last A fragments by then) and a second barrier publishes it before the next chunk's A fragments are read.
     constexpr int NS = BK / 16;
-    const int ntile = nchunk * TAPS;
+    static_assert(NS == 2 && WRING == 3 && TAPS % WRING == 0, "pipeline is written for two K steps per tap and a 3-slot ring");
+    constexpr int NAL = NA + (PRO != 0 ? 2 : 0);   // vector loads issued by loadA (all unconditional)
 #pragma unroll
-    for (int d = 0; d < D; ++d) { const int t = min(d, ntile - 1); gldsW(t / TAPS, t % TAPS, d); }
+    for (int d = 0; d < WRING; ++d) gldsW(0, d, d);
     TR();
     loadA(0);
     TR();
     storeA(0);
     TR();
-    int it = 0;
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+    // LDS byte addresses: one base VGPR per A fragment row set and one for the weights; everything else is an immediate
+    unsigned abase[FM];
 #pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap, ++it) {
-        // tile `it` is complete once at most (D-1)*NW of this thread's newer loads are outstanding (any extra ordinary
-        // loads issued since only make the wait stricter); the barrier then publishes every wave's part and also
-        // guarantees that every wave has finished reading tile it-1, whose buffer is refilled during this tap.
+    for (int fm = 0; fm < FM; ++fm) abase[fm] = (unsigned)(size_t)(__attribute__((address_space(3))) __bf16*)(sAh + hbase[fm]);
+    const unsigned wb = (unsigned)(size_t)(__attribute__((address_space(3))) __bf16*)(sW + wbase);
+    constexpr int ALO = APLANE * 2;          // byte offset of the lo plane
+    constexpr int WSLOT = TOTW * 16;         // bytes per ring slot
+    static_assert(ALO + (2 * TWIN + 2) * PITCH * 2 + 64 < 65536 && WRING * WSLOT < 65536, "LDS immediates must fit 16 bits");
+    // AOFF = halo pixel offset of a tap (elements), S = K step inside the tap, SLOT = ring slot
+#define LD_AL(AOFF, S) static_for<0, FM>([&](auto i) { al[i.value] = lds_read128<ALO + ((AOFF) + (S) * 16) * 2>(abase[i.value]); })
+#define LD_AH(AOFF, S) static_for<0, FM>([&](auto i) { ah[i.value] = lds_read128<((AOFF) + (S) * 16) * 2>(abase[i.value]); })
+#define LD_BH(SLOT, S) static_for<0, FN>([&](auto i) { bh[i.value] = lds_read128<(SLOT) * WSLOT + ((4 * (S)) * BN + i.value * 32) * 16>(wb); })
+#define LD_BL(SLOT, S) static_for<0, FN>([&](auto i) { bl[i.value] = lds_read128<(SLOT) * WSLOT + ((4 * (S) + 1) * BN + i.value * 32) * 16>(wb); })
+    auto X = [&]() {
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+    };
+    auto Z = [&]() {
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+    };
+    auto Y = [&]() {
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
+    };
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define FENCE() asm volatile("" ::: "memory")
+    LD_AL(0, 0); LD_BH(0, 0); LD_AH(0, 0); LD_BL(0, 0);
+    // The loop body is branch-free around the MFMAs (tail iterations prefetch clamped tiles and read fragments that are
+    // never used).  LDS reads complete in issue order, so "at most FM+FN reads outstanding" is the wait before every group
+    // in the steady state: the reads issued after the fragments a group needs are always exactly one a-set and one w-set.
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      const bool has_next = chunk + 1 < nchunk;
+      static_for<0, TAPS>([&](auto tapc) {
+        constexpr int tap = decltype(tapc)::value;
+        constexpr int aoff = ((tap / KS) * TWIN + (tap % KS)) * PITCH;
+        constexpr int aoff1 = (((tap + 1) / KS) * TWIN + ((tap + 1) % KS)) * PITCH;
+        constexpr int slot = tap % WRING, slotn = (tap + 1) % WRING;   // TAPS % WRING == 0: a tile's ring slot is tap % WRING
         TR();
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * NW) : "memory");
+        SB();
+        // outstanding on entry: a_lo, w_hi, a_hi, w_lo of (tap, step 0) in that order - after a chunk boundary a_lo, a_hi
+        lgkm_wait<(tap == 0) ? FM : FM + FN>(); SB();
+        X(); SB(); LD_AL(aoff, 1);
+        if (tap == 0) loadA(min(chunk + 1, nchunk - 1));     // next chunk's halo loads, in the MFMA shadow
+        SB();
+        lgkm_wait<(tap == 0) ? FM : FM + FN>(); SB();
+        Z(); SB(); LD_BH(slot, 1); SB();
+        lgkm_wait<FM + FN>(); SB();
+        Y();
+        if (has_next) {   // the next halo's normalise/activate/split arithmetic, spread over taps 2..7
+#pragma unroll
+          for (int i = 0; i < NA; ++i)
+            if (tap == 2 + (i * 6) / NA) transformPiece(i);
+        }
+        SB(); LD_AH(aoff, 1); LD_BL(slot, 1); SB();
+        lgkm_wait<FM + FN>(); SB();
+        X(); SB();
+        TR();
+        // the next tile must be complete.  This thread's outstanding vector loads, oldest first, are the next two weight
+        // tiles and (taps 0/1) the NAL halo loads issued during tap 0.  lgkmcnt(0): all reads of this ring slot are done.
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(tap <= 1 ? NW + NAL : NW) : "memory");
         TR();
         __builtin_amdgcn_s_barrier();
+        FENCE();
         TR();
-        const int aoff = ((tap / KS) * TWIN + (tap % KS)) * PITCH;
-        const __bf16* cW = sW + (it % WRING) * (TOTW * 8) + wbase;
-#pragma unroll
-        for (int s2 = 0; s2 < NS; ++s2) {
-          bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
-#pragma unroll
-          for (int fm = 0; fm < FM; ++fm) {
-            ah[fm] = *reinterpret_cast<const bf16x8*>(sAh + aoff + hbase[fm] + s2 * 16);
-            al[fm] = *reinterpret_cast<const bf16x8*>(sAl + aoff + hbase[fm] + s2 * 16);
-          }
-#pragma unroll
-          for (int fn = 0; fn < FN; ++fn) {
-            bh[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s2) * BN + fn * 32) * 8);
-            bl[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s2 + 1) * BN + fn * 32) * 8);
-          }
-#pragma unroll
-          for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
-#pragma unroll
-          for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
-          if (s2 == 0) {
-            // ... and the memory-side work is issued in the shadow of the MFMAs: the next ring slot's direct-to-LDS loads,
-            // the next chunk's halo loads (tap 0) and its normalise/activate/split arithmetic (tap 4)
-            const int t = min(it + D, ntile - 1);
-            gldsW(t / TAPS, t % TAPS, (it + D) % WRING);
-            if (tap == 0 && chunk + 1 < nchunk) loadA(chunk + 1);
-            if (chunk + 1 < nchunk) {   // pieces of the transform spread over taps 2..7, each hidden behind that tap's MFMAs
-#pragma unroll
-              for (int i = 0; i < NA; ++i)
-                if (tap == 2 + (i * 6) / NA) transformPiece(i);
-            }
-          }
-#pragma unroll
-          for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+        {
+          int c2 = chunk + (tap + WRING) / TAPS, t2 = (tap + WRING) % TAPS;
+          if (c2 >= nchunk) { c2 = nchunk - 1; t2 = TAPS - 1; }
+          gldsW(c2, t2, slot);
         }
-        asm volatile("s_nop 0" ::: "memory");
-        TR();
-        if (tap == TAPS - 1 && chunk + 1 < nchunk) {
+        if constexpr (tap == TAPS - 1) {
+          if (has_next) writeA(0);
+          SB();
+          Z(); SB(); LD_BH(slotn, 0); SB();
+          Y(); SB(); LD_BL(slotn, 0);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();   // every wave has finished reading this chunk's halo
-          writeA(0);                      // visible to all after the next iteration's barrier (lgkmcnt(0) precedes it)
+          __builtin_amdgcn_s_barrier();
+          FENCE();
+          LD_AL(0, 0); LD_AH(0, 0); SB();
+        } else {
+          LD_AL(aoff1, 0); SB();
+          Z(); SB(); LD_BH(slotn, 0); SB();
+          Y(); SB(); LD_AH(aoff1, 0); LD_BL(slotn, 0); SB();
         }
-      }
+      });
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail prefetches before the workgroup retires
+#undef LD_AL
+#undef LD_AH
+#undef LD_BH
+#undef LD_BL
+#undef FENCE
+#undef SB
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // drain the clamped tail prefetches before the workgroup retires
   }
 
   TR();
@@ -438,7 +503,7 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out;
   p.ksplit = conv_ksplit(a);
   p.partial = p.ksplit > 1 ? static_cast<float*>(a.splitk_ws) : nullptr;
-  p.qkv = a.qkv_planes;
+  p.qkv = a.qkv_planes; p.out_planes = a.out_planes;
   const int tile = conv_pick_tile(a);
   if (a.ks == 1) {
     switch (a.prologue) {

@@ -16,6 +16,7 @@ struct ConvP {
   float* out; int ld_out;
   float* stats;   // optional [B][tiles][N][2]: per-tile, per-channel (sum, sum of squares) of the stored outputs
   int tiles_x, tiles_y, nt;
+  void* out_planes;             // result as bf16 hi/lo planes [M][ld_out] | [M][ld_out] instead of fp32 (consumer: gemm_planes_bf3.hip)
   void* qkv;                    // fused q|k|v projection written as bf16 hi/lo planes for attention_bf3.hip (d_head 64)
   int ksplit; float* partial;   // split-K: raw accumulators to partial[split][M][N]; bias/residual/statistics happen in the reduce kernel
 };
@@ -36,6 +37,18 @@ __device__ __forceinline__ float erf_as_f(float x) {
   return copysignf(y, x);
 }
 __device__ __forceinline__ float gelu_erf_f(float g) { return 0.5f * g * (1.0f + erf_as_f(g * 0.70710678118654752440f)); }
+
+// one output element, either fp32 or as a bf16 (hi, lo = x - hi) pair in the two planes of out_planes
+__device__ __forceinline__ void store_out(const ConvP& p, size_t idx, float v) {
+  if (p.out_planes) {
+    __bf16* q = static_cast<__bf16*>(p.out_planes);
+    const __bf16 hi = (__bf16)v;
+    q[idx] = hi;
+    q[idx + (size_t)p.B * p.Hout * p.Wout * p.ld_out] = (__bf16)(v - (float)hi);
+  } else {
+    p.out[idx] = v;
+  }
+}
 
 // out[m][n] = acc + bias[n] + sbias[b][n] + res[m][n]   (or the GeGLU product), NHWC store.
 // When p.stats is set, the workgroup also emits the per-channel sum / sum-of-squares of what it stored, so that the
@@ -155,7 +168,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) {
           const float v = acc[fm][fn][r] + cb[fn];
-          p.out[m * p.ld_out + ncol[fn]] = v;
+          store_out(p, m * p.ld_out + ncol[fn], v);
           ssum[fn] += v; ssq[fn] += v * v;
         }
       }
@@ -177,7 +190,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
             if (j < p.N / 2) {
               float v = acc[fm][0][r], g = acc[fm][FN - 1][r];
               if (p.bias) { v += p.bias[nv]; g += p.bias[nv + 32]; }
-              p.out[m * p.ld_out + j] = v * gelu_erf_f(g);
+              store_out(p, m * p.ld_out + j, v * gelu_erf_f(g));
             }
           }
         } else {
@@ -189,7 +202,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
               if (p.bias) v += p.bias[n];
               if (sb) v += sb[n];
               if (p.res) v += p.res[m * p.ld_res + n];
-              p.out[m * p.ld_out + n] = v;
+              store_out(p, m * p.ld_out + n, v);
               ssum[fn] += v; ssq[fn] += v * v;
             }
           }

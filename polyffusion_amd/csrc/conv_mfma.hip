@@ -336,6 +336,9 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
              "conv: qkv planes need ks=1, N = 3*heads*64 and L %% 16 == 0");
 
   PF_REQUIRE(a.precision == PF_PREC_F32 || a.precision == PF_PREC_BF16X3, "conv: bad precision %d", a.precision);
+  PF_REQUIRE(!a.a_planes || (a.precision == PF_PREC_BF16X3 && a.ks == 1 && a.prologue == 0 && a.c1 == 0),
+             "conv: a_planes needs bf16x3, ks=1, no prologue, single source");
+  if (a.a_planes) return launch_gemm_planes(a, stream);
   if (a.precision == PF_PREC_BF16X3) return launch_conv_bf3(a, stream);
 
   ConvP p;
@@ -348,7 +351,7 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
   p.sc = a.sc; p.sh = a.sh; p.mean = a.mean; p.rstd = a.rstd;
   p.bias = a.bias; p.sbias = a.sbias; p.ld_sbias = a.ld_sbias; p.res = a.res; p.ld_res = a.ld_res;
   p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out;
-  p.ksplit = 1; p.partial = nullptr; p.qkv = a.qkv_planes;
+  p.ksplit = 1; p.partial = nullptr; p.qkv = a.qkv_planes; p.out_planes = a.out_planes;
 
   const int tile = conv_pick_tile(a);
 

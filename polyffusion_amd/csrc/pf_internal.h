@@ -42,7 +42,8 @@ void pack_gemm_bf3(void* dst, const float* src, int n_src, int K, int taps, int 
 int launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                      int batch, int n_heads, int d_head, int lq, int lk, hipStream_t stream);
 
-int launch_attention_bf3(const void* planes, float* o, int ldo, int batch, int n_heads, int l, hipStream_t stream);
+int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, hipStream_t stream);
+int launch_gemm_planes(const pf_conv_args& a, hipStream_t stream);   // called by launch_conv when a.a_planes
 
 size_t gn_scratch_bytes(int batch, int c, int hw);
 int launch_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batch, int hw, int groups, float eps,

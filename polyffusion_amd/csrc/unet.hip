@@ -504,6 +504,7 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
     c.conv(a, PF_K_GEMM);
   }
   float* t0 = ta; float* t1 = tbuf; float* t2 = tc;
+  bool last_planes = false;
   for (size_t i = 0; i < L.tbs.size(); ++i) {
     const Layer::TB& t = L.tbs[i];
     // x = attn1(LN1(x)) + x
@@ -518,12 +519,12 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
     }
     c.prof_begin(PF_K_ATTN, 4.0 * B * nh * (double)hw * hw * dh);
     if (!c.dry && c.rc == PF_OK)
-      c.rc = planes ? launch_attention_bf3(qkv, att, C, B, nh, hw, c.s)
+      c.rc = planes ? launch_attention_bf3(qkv, nullptr, C, att, B, nh, hw, c.s)   // att as hi/lo planes for the to_out GEMM
                     : launch_attention(qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, att, C, B, nh, dh, hw, hw, c.s);
     c.prof_end();
     {
       pf_conv_args a = conv_base(att, C, nullptr, 0, B, 1, hw, 1, c.w(t.o1w), C, t1);
-      a.bias = c.w(t.o1b); a.res = t0; a.ld_res = C;
+      a.bias = c.w(t.o1b); a.res = t0; a.ld_res = C; a.a_planes = planes ? 1 : 0;
       if (c.n_cond == 1) {  // x = attn2(LN2(x), c) + x collapses to a per-sample bias (softmax over one key == 1)
         a.sbias = c.dry ? nullptr : cross_all + t.cross_off;
         a.ld_sbias = c.u->cross_total;
@@ -558,11 +559,14 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
       pf_conv_args a = conv_base(t1, C, nullptr, 0, B, 1, hw, 1, c.w(t.ff1w), 8 * C, ff);
       a.prologue = 3; a.sc = c.w(t.n3g); a.sh = c.w(t.n3b); a.mean = mu; a.rstd = rs; a.bias = c.w(t.ff1b);
       a.geglu = 1; a.ld_out = 4 * C;
+      if (planes) a.out_planes = c.dry ? (void*)1 : (void*)ff;   // GeGLU product straight into hi/lo planes for the ff2 GEMM
       c.conv(a, PF_K_GEMM);
     }
     {
       pf_conv_args a = conv_base(ff, 4 * C, nullptr, 0, B, 1, hw, 1, c.w(t.ff2w), C, t2);
-      a.bias = c.w(t.ff2b); a.res = t1; a.ld_res = C;
+      a.bias = c.w(t.ff2b); a.res = t1; a.ld_res = C; a.a_planes = planes ? 1 : 0;
+      last_planes = planes && (i + 1 == L.tbs.size());
+      if (last_planes) a.out_planes = c.dry ? (void*)1 : (void*)t2;   // only proj_out reads it
       c.conv(a, PF_K_GEMM);
     }
     std::swap(t0, t2);
@@ -570,7 +574,7 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
   Tn ot;
   {
     pf_conv_args a = conv_base(t0, C, nullptr, 0, B, 1, hw, 1, c.w(L.pout_w), C, out);
-    a.bias = c.w(L.pout_b); a.res = x; a.ld_res = C;
+    a.bias = c.w(L.pout_b); a.res = x; a.ld_res = C; a.a_planes = last_planes ? 1 : 0;
     c.conv(a, PF_K_GEMM, &ot, true);
   }
   return ot;
@@ -846,8 +850,8 @@ int pf_conv2d(const pf_conv_args* a, void* stream) {
   PF_REQUIRE(a, "pf_conv2d: null argument");
   return launch_conv(*a, (hipStream_t)stream);
 }
-int pf_attention_bf16x3(const void* qkv_planes, float* o, int ldo, int batch, int n_heads, int l, void* stream) {
-  return launch_attention_bf3(qkv_planes, o, ldo, batch, n_heads, l, (hipStream_t)stream);
+int pf_attention_bf16x3(const void* qkv_planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, void* stream) {
+  return launch_attention_bf3(qkv_planes, o, ldo, o_planes, batch, n_heads, l, (hipStream_t)stream);
 }
 int pf_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int batch,
                  int n_heads, int d_head, int lq, int lk, void* stream) {

@@ -188,7 +188,71 @@ def test_qkv_planes_and_bf16x3_attention(lib, B, L, H):
     qrec = (pl[0] + pl[1]).view(B, L, c)
     assert (qrec - qkv[..., :c]).abs().max() < 3e-4
     out = torch.empty(B, L, c, device="cuda")
-    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, B, H, L, _lib.current_stream()))
+    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, None, B, H, L, _lib.current_stream()))
     torch.cuda.synchronize()
     err = (out.cpu() - ref).abs().max().item()
     assert err < 3e-4, err
+
+
+def _split_planes(x):
+    """fp32 [M][K] -> the bf16 hi|lo plane pair a producer epilogue writes (as a float32-typed byte buffer)."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi.reshape(-1), lo.reshape(-1)]).cuda().view(torch.float32)
+
+
+@pytest.mark.parametrize("B,L,k,n", [(2, 1024, 256, 256), (16, 256, 1024, 256), (3, 200, 64, 96), (1, 128, 32, 64)])
+def test_planes_gemm_chain(lib, B, L, k, n):
+    """Linear whose A operand arrives as pre-split planes (global->LDS direct), writing fp32 or planes again;
+    and a GeGLU projection that emits its product as planes (the ff1 -> ff2 -> proj_out chain of the transformer)."""
+    x = rnd((B, L, k), 91)
+    w, bias, res = rnd((n, k), 92, k ** -0.5), rnd((n,), 93, 0.1), rnd((B, L, n), 94)
+    ref = F.linear(x, w, bias) + res
+    ap = _split_planes(x)
+    out = torch.empty(B, L, n, device="cuda")
+    run_conv(lib, x0=ap, c0=k, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, w), n=n, bias=dev(bias),
+             res=dev(res), ld_res=n, out=out, ld_out=n, precision=1, a_planes=1)
+    assert (out.cpu() - ref).abs().max().item() < TOL_OP
+    # same GEMM, result as planes
+    op = torch.zeros(B * L * n, device="cuda")
+    run_conv(lib, x0=ap, c0=k, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, w), n=n, bias=dev(bias),
+             res=dev(res), ld_res=n, out=op, ld_out=n, precision=1, a_planes=1, out_planes=op)
+    pl = op.view(torch.bfloat16).float().cpu().view(2, B, L, n)
+    assert (pl[0] + pl[1] - ref).abs().max().item() < TOL_OP
+    # GeGLU projection from fp32 input -> planes, then consumed by a planes GEMM
+    if n % 64 == 0:
+        wg, bg = rnd((2 * n, k), 95, k ** -0.5), rnd((2 * n,), 96, 0.1)
+        h = F.linear(x, wg, bg)
+        gref = h[..., :n] * F.gelu(h[..., n:])
+        # interleaved GeGLU packing is the plan's job (unet.hip D_GEGLU_W): value/gate rows alternate in 32-column blocks
+        wi = torch.stack([wg[:n].view(n // 32, 32, k), wg[n:].view(n // 32, 32, k)], 1).reshape(2 * n, k)
+        bi = torch.stack([bg[:n].view(n // 32, 32), bg[n:].view(n // 32, 32)], 1).reshape(2 * n)
+        gp = torch.zeros(B * L * n, device="cuda")
+        run_conv(lib, x0=dev(x), c0=k, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, wi), n=2 * n,
+                 bias=dev(bi), geglu=1, out=gp, ld_out=n, precision=1, out_planes=gp)
+        pl = gp.view(torch.bfloat16).float().cpu().view(2, B, L, n)
+        assert (pl[0] + pl[1] - gref).abs().max().item() < TOL_OP
+        w2 = rnd((k, n), 97, n ** -0.5)
+        out2 = torch.empty(B, L, k, device="cuda")
+        run_conv(lib, x0=gp, c0=n, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, w2), n=k, out=out2, ld_out=k,
+                 precision=1, a_planes=1)
+        assert (out2.cpu() - F.linear(gref, w2)).abs().max().item() < TOL_OP
+
+
+def test_attention_planes_output(lib):
+    B, L, H = 2, 256, 4
+    c = H * 64
+    qkv = rnd((B, L, 3 * c), 101)
+    q, k, v = (t.reshape(B, L, H, 64) for t in qkv.chunk(3, dim=-1))
+    att = (torch.einsum("bihd,bjhd->bhij", q, k) * 0.125).softmax(-1)
+    ref = torch.einsum("bhij,bjhd->bihd", att, v).reshape(B, L, c)
+    planes = torch.zeros(B * L * 3 * c, dtype=torch.float32, device="cuda")
+    eye = torch.eye(3 * c)
+    dummy = torch.empty(1, device="cuda")
+    run_conv(lib, x0=dev(qkv), c0=3 * c, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, eye), n=3 * c,
+             out=dummy, ld_out=3 * c, precision=1, qkv_planes=planes)
+    op = torch.zeros(B * L * c, device="cuda")
+    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), None, c, op.data_ptr(), B, H, L, _lib.current_stream()))
+    torch.cuda.synchronize()
+    pl = op.view(torch.bfloat16).float().cpu().view(2, B, L, c)
+    assert (pl[0] + pl[1] - ref).abs().max().item() < 3e-4
