@@ -18,8 +18,6 @@
 //     consecutive-k B operands are one 16-byte LDS read per plane;
 //   * BK = 32; the 3x3 halo image is single-buffered (it changes every 9 taps; its global loads are
 //     issued three taps ahead), weight tiles are double-buffered; 1x1 mode double-buffers both.
-#include <type_traits>
-
 #include "conv_common.h"
 
 namespace pf {
@@ -31,25 +29,7 @@ __device__ unsigned long long g_trace[8192];
 #define TR() do {} while (0)
 #endif
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// LDS fragment read issued as inline asm, NOT as a C++ load: with direct-to-LDS loads in flight the compiler's wait-count
-// pass degrades every LDS dependency to lgkmcnt(0) (a pending global_load_lds counts as a "flat" access), which serialises
-// each ds_read with its MFMA.  The 3x3 loop therefore issues its reads here and places counted s_waitcnt lgkmcnt(N) itself.
-template <int OFF>
-__device__ __forceinline__ bf16x8 lds_read128(unsigned addr) {
-  u32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return __builtin_bit_cast(bf16x8, v);
-}
-template <int N>
-__device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
 
 template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM>
 __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
@@ -142,7 +122,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     for (int i = 0; i < NA; ++i) {
       // unconditional (padding / out-of-tile pieces read pixel 0 and are zeroed by the transform): the number of
       // vector loads in flight is then a compile-time constant, which the counted vmcnt waits of the 3x3 loop rely on
-      ra[i] = *reinterpret_cast<const f32x4*>(src + co + (unsigned)(max(poff[i], 0) * cs + c4 * 4));
+      if (KS == 3 || poff[i] >= 0) ra[i] = *reinterpret_cast<const f32x4*>(src + co + (unsigned)(max(poff[i], 0) * cs + c4 * 4));
+      else ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (PRO == 1 || PRO == 2) {
       vsc = *reinterpret_cast<const f32x4*>(p.sc + (size_t)b * cin + cg + c4 * 4);

@@ -2,9 +2,32 @@
 // and conv_bf16x3.hip (split bf16 MFMA).  Both kernels finish with the same 32x32 accumulator
 // fragments (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).
 #pragma once
+#include <type_traits>
+
 #include "pf_internal.h"
 
 namespace pf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// LDS fragment read issued as inline asm, NOT as a C++ load: with direct-to-LDS loads in flight the compiler's wait-count
+// pass degrades every LDS dependency to lgkmcnt(0) (a pending global_load_lds counts as a "flat" access), which serialises
+// each ds_read with its MFMA.  The direct-to-LDS pipelines (3x3 loop, planes GEMM, bf16x3 attention) issue their reads here and place counted
+// s_waitcnt lgkmcnt(N) themselves.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return __builtin_bit_cast(bf16x8, v);
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
 
 struct ConvP {
   const float* x0; const float* x1; int c0, c1;

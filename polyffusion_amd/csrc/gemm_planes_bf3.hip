@@ -11,11 +11,9 @@
 
 namespace pf {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
-  constexpr int BK = 32, RING = 3, D = RING - 1;
+  constexpr int BK = 32, RING = 3;
   constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 32, FN = WN / 32;
   constexpr int AU = 2 * BM * 4;            // 16-byte units of one A stage (2 planes x BM rows x 4 slots)
   constexpr int WU = 8 * BN;                // 16-byte units of one W stage (4 k8 x 2 planes x BN)
@@ -72,11 +70,21 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
                                        (__attribute__((address_space(3))) void*)(sb + AU * 8 + (wave * 64 + j * 256) * 8), 16, 0, 0);
   };
 
-  int aunit[FM];
+  // LDS byte addresses of this lane's fragments inside a stage.  The swizzled 16-byte slot of K step s is
+  // (2s + g) ^ sw = ((g ^ sw) & 1 | sw & 2) ^ 2s, so step 1 is step 0 with bit 1 flipped: two base registers per row set.
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) __bf16*)sm;
+  const int sw = ((lane & 31) >> 2) & 3;
+  const int x0 = (sw & 2) | (((lane >> 5) ^ sw) & 1);
+  unsigned abase[FM][2];
 #pragma unroll
-  for (int fm = 0; fm < FM; ++fm) aunit[fm] = (wm * WM + fm * 32 + (lane & 31)) * 4;
-  const int asw = ((lane & 31) >> 2) & 3;   // (row>>2)&3 of this lane's row (tile rows are multiples of 32 apart)
-  const int wbase = ((lane >> 5) * 2 * BN + wn * WN + (lane & 31)) * 8;
+  for (int fm = 0; fm < FM; ++fm) {
+    const int row = wm * WM + fm * 32 + (lane & 31);
+    abase[fm][0] = lds0 + (row * 4 + x0) * 16;
+    abase[fm][1] = lds0 + (row * 4 + (x0 ^ 2)) * 16;
+  }
+  const unsigned wb = lds0 + AU * 16 + (((lane >> 5) * 2 * BN + wn * WN + (lane & 31)) * 16);
+  constexpr int ALO = BM * 64;              // byte offset of the lo plane inside the A region
+  constexpr int STAGE_B = STAGE * 2;        // bytes per stage
 
   f32x16 acc[FM][FN];
 #pragma unroll
@@ -86,43 +94,72 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[fm][fn][r] = 0.f;
 
+  bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+  // S = K step (0/1), OFF = byte offset of the ring stage (runtime: added to the base register)
+#define LD_AL(S, OFF) static_for<0, FM>([&](auto i) { al[i.value] = lds_read128<ALO>(abase[i.value][S] + (OFF)); })
+#define LD_AH(S, OFF) static_for<0, FM>([&](auto i) { ah[i.value] = lds_read128<0>(abase[i.value][S] + (OFF)); })
+#define LD_BH(S, OFF) static_for<0, FN>([&](auto i) { bh[i.value] = lds_read128<((4 * (S)) * BN + i.value * 32) * 16>(wb + (OFF)); })
+#define LD_BL(S, OFF) static_for<0, FN>([&](auto i) { bl[i.value] = lds_read128<((4 * (S) + 1) * BN + i.value * 32) * 16>(wb + (OFF)); })
+#define SB() __builtin_amdgcn_sched_barrier(0)
+  auto X = [&]() {
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+  };
+  auto Z = [&]() {
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+  };
+  auto Y = [&]() {
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
+  };
+
+  // Same skewed single-fragment-set pipeline as the 3x3 loop of conv_bf16x3.hip: X = a_lo.w_hi, Z = a_hi.w_hi, Y = a_hi.w_lo;
+  // each fragment is re-loaded for the next K step right after its last reader, waits are counted by hand (FM+FN reads may
+  // stay outstanding before every group), one barrier per 32-deep chunk, and the stage read last is refilled three ahead.
   const int nchunk = K / BK;
 #pragma unroll
-  for (int d = 0; d < D; ++d) issue(min(d, nchunk - 1), d);
+  for (int d = 0; d < RING; ++d) issue(min(d, nchunk - 1), d);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * (NAu + NWu)) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  LD_AL(0, 0u); LD_BH(0, 0u); LD_AH(0, 0u); LD_BL(0, 0u);
+  int slot = 0;
   for (int chunk = 0; chunk < nchunk; ++chunk) {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * (NAu + NWu)) : "memory");
+    const unsigned so = slot * STAGE_B;
+    const int slotn = slot == RING - 1 ? 0 : slot + 1;
+    const unsigned son = slotn * STAGE_B;
+    SB();
+    lgkm_wait<FM + FN>(); SB();
+    X(); SB(); LD_AL(1, so); SB();
+    lgkm_wait<FM + FN>(); SB();
+    Z(); SB(); LD_BH(1, so); SB();
+    lgkm_wait<FM + FN>(); SB();
+    Y(); SB(); LD_AH(1, so); LD_BL(1, so); SB();
+    lgkm_wait<FM + FN>(); SB();
+    X(); SB();
+    // stage chunk+1 complete (this thread's newer stage may stay in flight), every read of stage `slot` done
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NAu + NWu) : "memory");
     __builtin_amdgcn_s_barrier();
-    const __bf16* st = sm + (chunk % RING) * STAGE;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
-#pragma unroll
-      for (int fm = 0; fm < FM; ++fm) {
-        const int unit = aunit[fm] + ((2 * s2 + (lane >> 5)) ^ asw);
-        ah[fm] = *reinterpret_cast<const bf16x8*>(st + unit * 8);
-        al[fm] = *reinterpret_cast<const bf16x8*>(st + (BM * 4 + unit) * 8);
-      }
-#pragma unroll
-      for (int fn = 0; fn < FN; ++fn) {
-        bh[fn] = *reinterpret_cast<const bf16x8*>(st + AU * 8 + wbase + ((4 * s2) * BN + fn * 32) * 8);
-        bl[fn] = *reinterpret_cast<const bf16x8*>(st + AU * 8 + wbase + ((4 * s2 + 1) * BN + fn * 32) * 8);
-      }
-#pragma unroll
-      for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
-      if (s2 == 0) issue(min(chunk + D, nchunk - 1), (chunk + D) % RING);   // refill the slot read one step ago, in the MFMA shadow
-#pragma unroll
-      for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
-#pragma unroll
-      for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
-    }
+    asm volatile("" ::: "memory");
+    issue(min(chunk + RING, nchunk - 1), slot);
+    LD_AL(0, son); SB();
+    Z(); SB(); LD_BH(0, son); SB();
+    Y(); SB(); LD_AH(0, son); LD_BL(0, son); SB();
+    slot = slotn;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef LD_AL
+#undef LD_AH
+#undef LD_BH
+#undef LD_BL
+#undef SB
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   conv_epilogue<1, BM, BN, FM, FN, 2>(p, acc, b, 0, ox0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem_raw));
 }

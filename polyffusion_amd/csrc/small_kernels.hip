@@ -181,47 +181,46 @@ int launch_time_embed(const int64_t* t, const float* w0, const float* b0, const 
 }
 
 // ------------------------------------------------------------------ batched mat-vec: y[b][n] = W[n][:] . x[b][:] + bias[n]
-// one wave per output n (8 outputs per wave), 8 batch rows per block so each weight row is read once per 8 samples.
+// A wave owns 8 outputs x 8 K-slices (lane = 8*o + j): the 8 lanes of an output stride its weight row in 128-byte
+// pieces, every lane keeps 8 batch-row accumulators, and the cross-lane reduction is 3 shuffles per accumulator.
+// 8 batch rows per block, so a weight row is read once per 8 samples; all loads of a K step are independent.
 __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ x0, int ldx, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y, int ldy, int B, int N,
                                                      int K, int n_per_group, int x_group_stride) {
-  constexpr int RB = 8, OPW = 8;
+  constexpr int RB = 8;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int o = lane >> 3, j = lane & 7;
   const int b0 = blockIdx.y * RB;
   const int nb = min(RB, B - b0);
-  const bool vec = (K % 4 == 0) && (ldx % 4 == 0);
-  for (int o = 0; o < OPW; ++o) {
-    const int n = (blockIdx.x * 4 + wave) * OPW + o;
-    if (n >= N) return;
-    const float* wr = w + (size_t)n * K;
-    const float* x = x0 + (size_t)(n / n_per_group) * x_group_stride;  // block-diagonal (grouped) form
-    float acc[RB];
+  const int n = (blockIdx.x * 4 + wave) * 8 + o;
+  const int nc = min(n, N - 1);                                       // out-of-range outputs compute a duplicate, never store
+  const float* wr = w + (size_t)nc * K;
+  const float* x = x0 + (size_t)(nc / n_per_group) * x_group_stride;  // block-diagonal (grouped) form
+  float acc[RB];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) acc[r] = 0.f;
-    if (vec) {
-      for (int k = lane * 4; k < K; k += 256) {
-        const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+  for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+  if ((K % 4 == 0) && (ldx % 4 == 0) && (x_group_stride % 4 == 0)) {
+#pragma unroll 2
+    for (int k = j * 4; k < K; k += 32) {
+      const float4 wv = *reinterpret_cast<const float4*>(wr + k);
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
-          if (r < nb) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)(b0 + r) * ldx + k);
-            acc[r] += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
-          }
-      }
-    } else {
-      for (int k = lane; k < K; k += 64) {
-        const float wv = wr[k];
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-          if (r < nb) acc[r] = fmaf(wv, x[(size_t)(b0 + r) * ldx + k], acc[r]);
+      for (int r = 0; r < RB; ++r) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)(b0 + min(r, nb - 1)) * ldx + k);
+        acc[r] += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
       }
     }
+  } else {
+    for (int k = j; k < K; k += 8) {
+      const float wv = wr[k];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      float v = acc[r];
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if (lane == 0 && r < nb) y[(size_t)(b0 + r) * ldy + n] = v + (bias ? bias[n] : 0.f);
+      for (int r = 0; r < RB; ++r) acc[r] = fmaf(wv, x[(size_t)(b0 + min(r, nb - 1)) * ldx + k], acc[r]);
     }
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    float v = acc[r];
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    if (j == 0 && n < N && r < nb) y[(size_t)(b0 + r) * ldy + n] = v + (bias ? bias[n] : 0.f);
   }
 }
 

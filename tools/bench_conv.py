@@ -27,6 +27,11 @@ SHAPES = [
     ("g1024_1024_256", 16, 1, 1024, 1024, 0, 256, 1, 1, 0, 0),
     ("g256_256_256", 16, 1, 256, 256, 0, 256, 1, 1, 0, 0),
     ("skip128_192_64", 16, 1, 16384, 128, 64, 64, 1, 1, 0, 0),
+    # A operand as pre-split bf16 hi/lo planes (gemm_planes_bf3.hip)
+    ("p1024_256_256", 16, 1, 1024, 256, 0, 256, 1, 1, 0, 0, 1),
+    ("p1024_1024_256", 16, 1, 1024, 1024, 0, 256, 1, 1, 0, 0, 1),
+    ("p256_256_256", 16, 1, 256, 256, 0, 256, 1, 1, 0, 0, 1),
+    ("p256_1024_256", 16, 1, 256, 1024, 0, 256, 1, 1, 0, 0, 1),
 ]
 
 
@@ -34,7 +39,10 @@ def main():
     prec = 1 if (len(sys.argv) < 2 or sys.argv[1] == "bf16x3") else 0
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
     lib = _lib.load()
-    for name, B, H, W, c0, c1, n, ks, stride, ups, pro in SHAPES:
+    for name, B, H, W, c0, c1, n, ks, stride, ups, pro, *rest in SHAPES:
+        planes = bool(rest and rest[0])
+        if planes and not prec:
+            continue
         if flt and flt not in name:
             continue
         cin = c0 + c1
@@ -55,6 +63,7 @@ def main():
         a.sc, a.sh, a.mean, a.rstd = sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), rstd.data_ptr()
         a.bias, a.res, a.ld_res = bias.data_ptr(), res.data_ptr(), n
         a.out, a.ld_out, a.precision = out.data_ptr(), n, prec
+        a.a_planes = int(planes)   # same bytes as fp32 [M][K]: the random bits are fine for timing
         st = torch.cuda.current_stream().cuda_stream
         for _ in range(3):
             _lib.check(lib.pf_conv2d(C.byref(a), st))
