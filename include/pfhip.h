@@ -150,6 +150,9 @@ int pf_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batc
                       void* scratch, size_t scratch_bytes, void* stream);
 /* LayerNorm statistics over the last dim: mean[m], rstd[m] (unet_attention.py:104-110, eps 1e-5). */
 int pf_ln_stats(const float* x, int rows, int c, float eps, float* mean, float* rstd, void* stream);
+/* LayerNorm applied and split into bf16 hi/lo planes [rows][c] | [rows][c] (the A operand of pf_conv2d with a_planes=1);
+ * replaces pf_ln_stats + the LayerNorm GEMM prologue for the transformer block's q/k/v and GeGLU projections */
+int pf_ln_planes(const float* x, int rows, int c, float eps, const float* gamma, const float* beta, void* planes, void* stream);
 
 /* Implicit-GEMM convolution / linear on NHWC with fused prologue and epilogue (fp32 MFMA).
  *   ks 1|3, stride 1|2, ups 0|1 (nearest x2 folded into the input read, unet.py:236-238)

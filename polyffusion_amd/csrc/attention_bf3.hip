@@ -12,11 +12,10 @@
 // statistics are lane-local and the fp32 accumulators of S^T, after exp and the hi/lo split, ARE the B operands
 // of the second product.  LDS rows are 128 B; the 16-byte slot index is XOR-swizzled with (row & 7) on the source
 // address of the direct load and on the fragment read, so ds_read_b128 over 32 consecutive rows is <= 2-way.
-#include "pf_internal.h"
+#include "conv_common.h"   // lds_read128 / lgkm_wait / static_for
 
 namespace pf {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct AttnP3 {
@@ -75,38 +74,53 @@ __global__ __launch_bounds__(256, 2) void attn_bf3_kernel(AttnP3 p) {
     for (int r = 0; r < 16; ++r) oacc[df][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntile = L / KT;
-  issue_tile(0, 0);
+  const int ntile = L / KT;            // even: L is a multiple of 128
   const int r31 = lane & 31;
-  for (int t = 0; t < ntile; ++t) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                       // every wave is done with the stage refilled next
-    if (t + 1 < ntile) {
-      issue_tile(t + 1, (t + 1) & 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this thread's part of tile t has landed (8 newer loads in flight)
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                       // tile t visible to all waves
-    const __bf16* st = sm + (t & 1) * STAGE;
+  // LDS byte address of this lane's fragment row inside an 8 KB array, one per K-step pair: row = r31 (+32 per fragment,
+  // an immediate), 16-byte slot = (2 sp + g) ^ (row & 7).  K and V^T fragments share the formula (row = key or channel).
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) __bf16*)sm;
+  unsigned faddr[4];
+#pragma unroll
+  for (int sp = 0; sp < 4; ++sp) faddr[sp] = lds0 + r31 * 128 + (((2 * sp + g) ^ (r31 & 7)) * 16);
+  constexpr int STAGE_B = STAGE * 2, ARR_B = KT * DH * 2;
+#define SB() __builtin_amdgcn_sched_barrier(0)
 
-    // ---- S^T = K . Q^T ----
+  // One tile = 16 "steps" of {two ds_read_b128 (hi, lo), three MFMAs}; the reads of step i+1 are issued before the MFMAs of
+  // step i and waited for with a counted lgkmcnt (inline asm reads - see conv_common.h), so the matrix pipe never waits
+  // for an LDS round trip.  One barrier per tile: it publishes tile t and frees the other stage for tile t+1.
+  auto tile_body = [&](auto stc, int t) {
+    constexpr int ST = decltype(stc)::value;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_tile(min(t + 1, ntile - 1), ST ^ 1);
+
+    // ---- S^T = K . Q^T : step i -> K-step pair sp = i >> 1, key fragment kf = i & 1 ----
     f32x16 s[2];
 #pragma unroll
-    for (int kf = 0; kf < 2; ++kf) {
+    for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kf][r] = 0.f;
-      const int key = kf * 32 + r31;
-#pragma unroll
-      for (int sp = 0; sp < 4; ++sp) {
-        const int unit = key * 8 + ((2 * sp + g) ^ (key & 7));
-        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(st + unit * 8);
-        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(st + KT * DH + unit * 8);
-        s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[sp], s[kf], 0, 0, 0);
-        s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[sp], s[kf], 0, 0, 0);
-        s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[sp], s[kf], 0, 0, 0);
+    bf16x8 fh[2], fl[2];
+    fh[0] = lds_read128<ST * STAGE_B>(faddr[0]);
+    fl[0] = lds_read128<ST * STAGE_B + ARR_B>(faddr[0]);
+    static_for<0, 8>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, sp = i >> 1, kf = i & 1, b = i & 1;
+      SB();
+      if constexpr (i < 7) {
+        constexpr int sp1 = (i + 1) >> 1, kf1 = (i + 1) & 1;
+        fh[b ^ 1] = lds_read128<ST * STAGE_B + kf1 * 4096>(faddr[sp1]);
+        fl[b ^ 1] = lds_read128<ST * STAGE_B + ARR_B + kf1 * 4096>(faddr[sp1]);
+      } else {   // first V^T fragments, in flight across the softmax
+        fh[b ^ 1] = lds_read128<ST * STAGE_B + 2 * ARR_B>(faddr[0]);
+        fl[b ^ 1] = lds_read128<ST * STAGE_B + 3 * ARR_B>(faddr[0]);
       }
-    }
+      lgkm_wait<2>(); SB();
+      s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b], qh[sp], s[kf], 0, 0, 0);
+      s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], ql[sp], s[kf], 0, 0, 0);
+      s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], qh[sp], s[kf], 0, 0, 0);
+      SB();
+    });
     // ---- online softmax (lane holds 32 keys of its query, the partner lane^32 the other 32) ----
     float mx = -INFINITY;
 #pragma unroll
@@ -128,29 +142,40 @@ __global__ __launch_bounds__(256, 2) void attn_bf3_kernel(AttnP3 p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[df][r] *= alpha;
 
-    // ---- O^T += V^T . P^T : registers 8kb'..8kb'+7 of a fragment are this lane's 8 keys of 16-key block kb ----
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      bf16x8 ph, pl;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = s[kb >> 1][(kb & 1) * 8 + j];
-        const __bf16 hi = (__bf16)v;
-        ph[j] = hi;
-        pl[j] = (__bf16)(v - (float)hi);
+    // ---- O^T += V^T . P^T : step j -> 16-key block kb = j >> 1, channel fragment df = j & 1; registers 8kb'..8kb'+7 of a
+    // score fragment are this lane's 8 keys of block kb.  Step 0's fragments sit in buffer 0 (loaded by S step 7). ----
+    bf16x8 ph, pl;
+    static_for<0, 8>([&](auto jc) {
+      constexpr int j = decltype(jc)::value, kb = j >> 1, df = j & 1, b = j & 1;
+      SB();
+      if constexpr (j < 7) {
+        constexpr int kb1 = (j + 1) >> 1, df1 = (j + 1) & 1;
+        fh[b ^ 1] = lds_read128<ST * STAGE_B + 2 * ARR_B + df1 * 4096>(faddr[kb1]);
+        fl[b ^ 1] = lds_read128<ST * STAGE_B + 3 * ARR_B + df1 * 4096>(faddr[kb1]);
       }
+      if constexpr (df == 0) {
 #pragma unroll
-      for (int df = 0; df < 2; ++df) {
-        const int d = df * 32 + r31;
-        const int unit = d * 8 + ((2 * kb + g) ^ (d & 7));
-        const bf16x8 vh = *reinterpret_cast<const bf16x8*>(st + 2 * KT * DH + unit * 8);
-        const bf16x8 vl = *reinterpret_cast<const bf16x8*>(st + 3 * KT * DH + unit * 8);
-        oacc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc[df], 0, 0, 0);
-        oacc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, oacc[df], 0, 0, 0);
-        oacc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc[df], 0, 0, 0);
+        for (int q = 0; q < 8; ++q) {
+          const float v = s[kb >> 1][(kb & 1) * 8 + q];
+          const __bf16 hi = (__bf16)v;
+          ph[q] = hi;
+          pl[q] = (__bf16)(v - (float)hi);
+        }
       }
-    }
+      lgkm_wait<(j < 7) ? 2 : 0>(); SB();
+      oacc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b], ph, oacc[df], 0, 0, 0);
+      oacc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], pl, oacc[df], 0, 0, 0);
+      oacc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], ph, oacc[df], 0, 0, 0);
+      SB();
+    });
+  };
+  issue_tile(0, 0);
+  for (int t = 0; t < ntile; t += 2) {
+    tile_body(std::integral_constant<int, 0>{}, t);
+    tile_body(std::integral_constant<int, 1>{}, t + 1);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail prefetch
+#undef SB
 
   const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
   float* op = p.o + ((size_t)b * L + qi) * p.ldo + h * DH;

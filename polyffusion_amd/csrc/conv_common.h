@@ -61,17 +61,7 @@ __device__ __forceinline__ float erf_as_f(float x) {
 }
 __device__ __forceinline__ float gelu_erf_f(float g) { return 0.5f * g * (1.0f + erf_as_f(g * 0.70710678118654752440f)); }
 
-// one output element, either fp32 or as a bf16 (hi, lo = x - hi) pair in the two planes of out_planes
-__device__ __forceinline__ void store_out(const ConvP& p, size_t idx, float v) {
-  if (p.out_planes) {
-    __bf16* q = static_cast<__bf16*>(p.out_planes);
-    const __bf16 hi = (__bf16)v;
-    q[idx] = hi;
-    q[idx + (size_t)p.B * p.Hout * p.Wout * p.ld_out] = (__bf16)(v - (float)hi);
-  } else {
-    p.out[idx] = v;
-  }
-}
+__device__ __forceinline__ void store_out(const ConvP& p, size_t idx, float v) { p.out[idx] = v; }
 
 // out[m][n] = acc + bias[n] + sbias[b][n] + res[m][n]   (or the GeGLU product), NHWC store.
 // When p.stats is set, the workgroup also emits the per-channel sum / sum-of-squares of what it stored, so that the
@@ -97,6 +87,78 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
           if (n < p.N) p.partial[m * p.N + n] = acc[fm][fn][r];
         }
       }
+    return;
+  }
+  // Destination of a plane-pair tile: the generic out_planes tensor, or - for a q|k|v projection tile that lies inside the
+  // Q or the K third - that third's [token][C] plane pair (the V third keeps its transposed layout below).
+  __bf16* pq = static_cast<__bf16*>(p.out_planes);
+  size_t pq_plane = (size_t)p.B * p.Hout * p.Wout * p.ld_out;
+  int pq_ld = p.ld_out, pq_n0 = p.geglu ? n0 / 2 : n0, pq_n = p.geglu ? p.N / 2 : p.N;
+  if (p.qkv) {
+    const int C = p.N / 3, which = n0 / C;
+    pq = nullptr;
+    if (C % BN == 0 && which < 2) {
+      pq_plane = (size_t)p.B * p.Wout * C;
+      pq = static_cast<__bf16*>(p.qkv) + (size_t)(2 * which) * pq_plane;
+      pq_ld = C; pq_n0 = n0 - which * C; pq_n = C;
+    }
+  }
+  if (pq) {
+    const float* sb = (p.sbias && !p.qkv) ? p.sbias + (size_t)b * p.ld_sbias : nullptr;
+    const float* resp = p.qkv ? nullptr : p.res;
+    // hi/lo plane output (linear layers only, TH == 1): the finished tile is transposed through LDS as fp32 so that the
+    // split and the global stores run row-wise - 16 bytes per lane per plane, whole 128-byte lines - instead of one 2-byte
+    // store per element from the column-per-lane accumulator layout.
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    const int L = p.Wout;
+    const int bno = p.geglu ? BN / 2 : BN;         // output columns of this tile
+    const int pitch = bno + 8;                     // floats; +8 keeps the two half-waves (rows r, r+4) on different banks
+    __syncthreads();                               // nobody is still reading the main loop's LDS images
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+      if (p.geglu) {
+        if constexpr (FN == 2) {
+          const int nv = n0 + wn * WN + (lane & 31);  // packed column of the value half; gate = nv + 32
+          const float bv = p.bias ? p.bias[nv] : 0.f, bg = p.bias ? p.bias[nv + 32] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = wm * WM + fm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            red[rl * pitch + wn * (WN / 2) + (lane & 31)] = (acc[fm][0][r] + bv) * gelu_erf_f(acc[fm][1][r] + bg);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+          const int cl = wn * WN + fn * 32 + (lane & 31), n = n0 + cl;
+          const bool nok = n < p.N;
+          const float cb = nok ? (p.bias ? p.bias[n] : 0.f) + (sb ? sb[n] : 0.f) : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = wm * WM + fm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float v = acc[fm][fn][r] + cb;
+            if (resp && nok && ox0 + rl < L) v += resp[((size_t)b * L + ox0 + rl) * p.ld_res + n];
+            red[rl * pitch + cl] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int cpr = bno / 8;
+    for (int idx = tid; idx < TH * TW * cpr; idx += NWM * 128) {
+      const int rl = idx / cpr, col = (idx - rl * cpr) * 8;
+      if (ox0 + rl >= L || pq_n0 + col >= pq_n) continue;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(red + rl * pitch + col);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(red + rl * pitch + col + 4);
+      bf16x8_t hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hi[j] = (__bf16)a[j]; lo[j] = (__bf16)(a[j] - (float)hi[j]);
+        hi[4 + j] = (__bf16)c[j]; lo[4 + j] = (__bf16)(c[j] - (float)hi[4 + j]);
+      }
+      const size_t o = ((size_t)b * L + ox0 + rl) * pq_ld + pq_n0 + col;
+      *reinterpret_cast<bf16x8_t*>(pq + o) = hi;
+      *reinterpret_cast<bf16x8_t*>(pq + pq_plane + o) = lo;
+    }
     return;
   }
   if (p.qkv) {

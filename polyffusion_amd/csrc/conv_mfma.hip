@@ -336,6 +336,9 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
              "conv: qkv planes need ks=1, N = 3*heads*64 and L %% 16 == 0");
 
   PF_REQUIRE(a.precision == PF_PREC_F32 || a.precision == PF_PREC_BF16X3, "conv: bad precision %d", a.precision);
+  PF_REQUIRE(!a.out_planes || (a.precision == PF_PREC_BF16X3 && a.ks == 1 && !a.stats_out && a.ld_out % 8 == 0 &&
+                               (a.geglu ? a.n / 2 : a.n) % 8 == 0),
+             "conv: out_planes needs bf16x3, ks=1, no statistics, ld_out and n multiples of 8");
   PF_REQUIRE(!a.a_planes || (a.precision == PF_PREC_BF16X3 && a.ks == 1 && a.prologue == 0 && a.c1 == 0),
              "conv: a_planes needs bf16x3, ks=1, no prologue, single source");
   if (a.a_planes) return launch_gemm_planes(a, stream);

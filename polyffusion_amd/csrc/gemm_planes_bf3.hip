@@ -11,9 +11,9 @@
 
 namespace pf {
 
-template <int BM, int BN>
+template <int BM, int BN, int RING>
 __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
-  constexpr int BK = 32, RING = 3;
+  constexpr int BK = 32;
   constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 32, FN = WN / 32;
   constexpr int AU = 2 * BM * 4;            // 16-byte units of one A stage (2 planes x BM rows x 4 slots)
   constexpr int WU = 8 * BN;                // 16-byte units of one W stage (4 k8 x 2 planes x BN)
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
     lgkm_wait<FM + FN>(); SB();
     X(); SB();
     // stage chunk+1 complete (this thread's newer stage may stay in flight), every read of stage `slot` done
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NAu + NWu) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 2) * (NAu + NWu)) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     issue(min(chunk + RING, nchunk - 1), slot);
@@ -164,11 +164,12 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
   conv_epilogue<1, BM, BN, FM, FN, 2>(p, acc, b, 0, ox0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem_raw));
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int RING>
 static int launch_gp(ConvP& p, hipStream_t stream) {
-  constexpr size_t lds = (size_t)3 * (2 * BM * 4 + 8 * BN) * 16;
+  constexpr size_t ring = (size_t)RING * (2 * BM * 4 + 8 * BN) * 16, epi = (size_t)BM * (BN + 8) * 4;   // epi: planes-output transpose
+  constexpr size_t lds = ring > epi ? ring : epi;
   p.tiles_x = cdiv(p.Wout, BM); p.tiles_y = 1; p.nt = cdiv(p.Npad, BN);
-  auto kern = gemm_planes_kernel<BM, BN>;
+  auto kern = gemm_planes_kernel<BM, BN, RING>;
   static bool done = false;
   if (!done) { PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
   hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_x * p.nt), dim3(256), lds, stream, p);
@@ -183,12 +184,13 @@ int launch_gemm_planes(const pf_conv_args& a, hipStream_t stream) {
   p.x0 = a.x0; p.c0 = a.c0; p.B = a.batch; p.Hin = 1; p.Win = a.win; p.Hout = 1; p.Wout = a.win;
   p.w = a.w; p.N = a.n; p.Npad = (a.n + 63) / 64 * 64;
   p.bias = a.bias; p.sbias = a.sbias; p.ld_sbias = a.ld_sbias; p.res = a.res; p.ld_res = a.ld_res;
-  p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out; p.out_planes = a.out_planes;
+  p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out; p.out_planes = a.out_planes; p.qkv = a.qkv_planes;
   p.ksplit = 1;
   const int tile = conv_pick_tile(a);
-  if (tile == 0) return launch_gp<128, 128>(p, stream);
-  if (tile == 1) return launch_gp<128, 64>(p, stream);
-  return launch_gp<64, 64>(p, stream);   // same row tiling as the register path: the GroupNorm statistics tiles must agree
+  // ring depth: the deepest that still lets two workgroups share a CU's 160 KB (a 128x128 stage is 32 KB)
+  if (tile == 0) return launch_gp<128, 128, 2>(p, stream);
+  if (tile == 1) return launch_gp<128, 64, 3>(p, stream);
+  return launch_gp<64, 64, 3>(p, stream);   // same row tiling as the register path: the GroupNorm statistics tiles must agree
 }
 
 }  // namespace pf

@@ -150,6 +150,61 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
   }
 }
 
+// LayerNorm applied and split into the bf16 hi/lo planes a planes GEMM (gemm_planes_bf3.hip) streams straight into LDS:
+// y = (x - mean) * rstd * gamma + beta, same operation order as the GEMM-prologue form.  One wave per row, the row stays
+// in registers between the statistics and the output (C <= 1024), so x is read once: 4 B in, 4 B out per element.
+typedef __bf16 bf16x4_n __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void ln_planes_kernel(const float* __restrict__ x, int rows, int C, float eps,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        __bf16* __restrict__ planes) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * C;
+  f32x4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = lane * 4 + i * 256;
+    if (k < C) { v[i] = *reinterpret_cast<const f32x4*>(xr + k); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mu = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = lane * 4 + i * 256;
+    if (k < C) {
+      const float a = v[i][0] - mu, b = v[i][1] - mu, c = v[i][2] - mu, d = v[i][3] - mu;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rs = 1.0f / sqrtf(q / (float)C + eps);
+  const size_t MC = (size_t)rows * C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = lane * 4 + i * 256;
+    if (k < C) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + k), be = *reinterpret_cast<const f32x4*>(beta + k);
+      const f32x4 y = (v[i] - mu) * rs * g + be;
+      const bf16x4_n hi = __builtin_convertvector(y, bf16x4_n);
+      const bf16x4_n lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x4), bf16x4_n);
+      *reinterpret_cast<bf16x4_n*>(planes + (size_t)row * C + k) = hi;
+      *reinterpret_cast<bf16x4_n*>(planes + MC + (size_t)row * C + k) = lo;
+    }
+  }
+}
+
+int launch_ln_planes(const float* x, int rows, int c, float eps, const float* gamma, const float* beta, void* planes,
+                     hipStream_t stream) {
+  PF_REQUIRE(x && gamma && beta && planes && rows > 0 && c > 0 && c % 4 == 0 && c <= 1024, "ln_planes: bad arguments (c=%d)", c);
+  hipLaunchKernelGGL(ln_planes_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, rows, c, eps, gamma, beta,
+                     static_cast<__bf16*>(planes));
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
 int launch_ln_stats(const float* x, int rows, int c, float eps, float* mean, float* rstd, hipStream_t stream) {
   PF_REQUIRE(x && mean && rstd && rows > 0 && c > 0 && c % 4 == 0, "ln_stats: bad arguments");
   hipLaunchKernelGGL(ln_stats_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, rows, c, eps, mean, rstd);

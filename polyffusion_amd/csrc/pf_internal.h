@@ -55,6 +55,8 @@ int launch_gn_finalize_tiles(const float* s0, int t0, int c0, const float* s1, i
 int gn_nsplit(int hw);
 int launch_gn_partial(const float* x0, int c0, const float* x1, int c1, int batch, int hw, float* stats, hipStream_t stream);
 int launch_ln_stats(const float* x, int rows, int c, float eps, float* mean, float* rstd, hipStream_t stream);
+int launch_ln_planes(const float* x, int rows, int c, float eps, const float* gamma, const float* beta, void* planes,
+                     hipStream_t stream);
 
 // stem / head convolutions (NCHW <-> NHWC at the ABI edge)
 int launch_conv_in(const float* x_nchw, const float* w /*[Cout][Cin][3][3]*/, const float* bias, float* out_nhwc,

@@ -435,6 +435,11 @@ struct Ctx {
     prof_end();
     x.st = sb; x.nt = ns;
   }
+  void lnp(const float* x, int rows, int c, size_t gamma, size_t beta, float* planes) {   // LayerNorm -> hi/lo planes
+    prof_begin(PF_K_LNSTAT, 0.0);
+    if (!dry && rc == PF_OK) rc = launch_ln_planes(x, rows, c, 1e-5f, w(gamma), w(beta), planes, s);
+    prof_end();
+  }
   void ln(const float* x, int rows, int c, float* mu, float* rs) {
     prof_begin(PF_K_LNSTAT, 0.0);
     if (!dry && rc == PF_OK) rc = launch_ln_stats(x, rows, c, 1e-5f, mu, rs, s);
@@ -508,13 +513,20 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
   for (size_t i = 0; i < L.tbs.size(); ++i) {
     const Layer::TB& t = L.tbs[i];
     // x = attn1(LN1(x)) + x
-    c.ln(t0, M, C, mu, rs);
-    // bf16x3 mode, d_head 64, L % 128 == 0: the projection writes pre-split q/k/v^T planes and attention runs on the bf16 pipe
-    const bool planes = c.u->precision == PF_PREC_BF16X3 && dh == 64 && hw % 128 == 0 && C % 32 == 0;
-    {
+    // bf16x3 mode, d_head 64, L % 128 == 0: every linear layer of the block runs as a planes GEMM (both operands stream
+    // global->LDS): LayerNorm is applied once per row into hi/lo planes instead of once per column tile in a GEMM prologue,
+    // the projection writes pre-split q/k/v^T planes and attention runs on the bf16 pipe
+    const bool planes = c.u->precision == PF_PREC_BF16X3 && dh == 64 && hw % 128 == 0 && C % 32 == 0 && C <= 1024;
+    if (planes) {
+      c.lnp(t0, M, C, t.n1g, t.n1b, att);   // `att` is free until attention writes it
+      pf_conv_args a = conv_base(att, C, nullptr, 0, B, 1, hw, 1, c.w(t.qkv), 3 * C, qkv);
+      a.a_planes = 1;
+      a.qkv_planes = c.dry ? (void*)1 : (void*)qkv;   // same bytes as the fp32 [M][3C] buffer
+      c.conv(a, PF_K_GEMM);
+    } else {
+      c.ln(t0, M, C, mu, rs);
       pf_conv_args a = conv_base(t0, C, nullptr, 0, B, 1, hw, 1, c.w(t.qkv), 3 * C, qkv);
       a.prologue = 3; a.sc = c.w(t.n1g); a.sh = c.w(t.n1b); a.mean = mu; a.rstd = rs;
-      if (planes) a.qkv_planes = c.dry ? (void*)1 : (void*)qkv;   // same bytes as the fp32 [M][3C] buffer
       c.conv(a, PF_K_GEMM);
     }
     c.prof_begin(PF_K_ATTN, 4.0 * B * nh * (double)hw * hw * dh);
@@ -554,12 +566,17 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
       std::swap(t1, t2);
     }
     // x = ff(LN3(x)) + x
-    c.ln(t1, M, C, mu, rs);
-    {
+    if (planes) {
+      c.lnp(t1, M, C, t.n3g, t.n3b, att);   // `att` has been consumed by to_out
+      pf_conv_args a = conv_base(att, C, nullptr, 0, B, 1, hw, 1, c.w(t.ff1w), 8 * C, ff);
+      a.a_planes = 1; a.bias = c.w(t.ff1b); a.geglu = 1; a.ld_out = 4 * C;
+      a.out_planes = c.dry ? (void*)1 : (void*)ff;   // GeGLU product straight into hi/lo planes for the ff2 GEMM
+      c.conv(a, PF_K_GEMM);
+    } else {
+      c.ln(t1, M, C, mu, rs);
       pf_conv_args a = conv_base(t1, C, nullptr, 0, B, 1, hw, 1, c.w(t.ff1w), 8 * C, ff);
       a.prologue = 3; a.sc = c.w(t.n3g); a.sh = c.w(t.n3b); a.mean = mu; a.rstd = rs; a.bias = c.w(t.ff1b);
       a.geglu = 1; a.ld_out = 4 * C;
-      if (planes) a.out_planes = c.dry ? (void*)1 : (void*)ff;   // GeGLU product straight into hi/lo planes for the ff2 GEMM
       c.conv(a, PF_K_GEMM);
     }
     {
@@ -835,6 +852,9 @@ int pf_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batc
                       const float* gamma, const float* beta, float* scale, float* shift, void* scratch, size_t scratch_bytes,
                       void* stream) {
   return launch_gn_scale_shift(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, scale, shift, scratch, scratch_bytes, (hipStream_t)stream);
+}
+int pf_ln_planes(const float* x, int rows, int c, float eps, const float* gamma, const float* beta, void* planes, void* stream) {
+  return launch_ln_planes(x, rows, c, eps, gamma, beta, planes, (hipStream_t)stream);
 }
 int pf_ln_stats(const float* x, int rows, int c, float eps, float* mean, float* rstd, void* stream) {
   return launch_ln_stats(x, rows, c, eps, mean, rstd, (hipStream_t)stream);

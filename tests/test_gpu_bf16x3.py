@@ -256,3 +256,33 @@ def test_attention_planes_output(lib):
     torch.cuda.synchronize()
     pl = op.view(torch.bfloat16).float().cpu().view(2, B, L, c)
     assert (pl[0] + pl[1] - ref).abs().max().item() < 3e-4
+
+
+@pytest.mark.parametrize("B,L,H", [(2, 1024, 4), (3, 256, 4)])
+def test_ln_planes_feeds_the_projection(lib, B, L, H):
+    """LayerNorm applied once into hi/lo planes (pf_ln_planes), consumed by the q|k|v planes GEMM and the bf16x3 attention:
+    the all-planes form of the transformer block's first half."""
+    c = H * 64
+    x = rnd((B, L, c), 111) * 1.3 + 0.2
+    gamma, beta = 1 + 0.1 * rnd((c,), 112), 0.1 * rnd((c,), 113)
+    w = rnd((3 * c, c), 114, c ** -0.5) * 1.5
+    xn = F.layer_norm(x, (c,), gamma, beta)
+    qkv = F.linear(xn, w)
+    q, k, v = (t.reshape(B, L, H, 64) for t in qkv.chunk(3, dim=-1))
+    att = (torch.einsum("bihd,bjhd->bhij", q, k) * 0.125).softmax(-1)
+    ref = torch.einsum("bhij,bjhd->bihd", att, v).reshape(B, L, c)
+    xd = dev(x)
+    lnp = torch.zeros(B * L * c, device="cuda")
+    gd, bd = dev(gamma), dev(beta)
+    _lib.check(lib.pf_ln_planes(xd.data_ptr(), B * L, c, 1e-5, gd.data_ptr(), bd.data_ptr(), lnp.data_ptr(),
+                                _lib.current_stream()))
+    pl = lnp.view(torch.bfloat16).float().cpu().view(2, B, L, c)
+    assert (pl[0] + pl[1] - xn).abs().max().item() < 1e-4
+    planes = torch.zeros(B * L * 3 * c, dtype=torch.float32, device="cuda")
+    dummy = torch.empty(1, device="cuda")
+    run_conv(lib, x0=lnp, c0=c, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, w), n=3 * c, out=dummy, ld_out=3 * c,
+             precision=1, a_planes=1, qkv_planes=planes)
+    out = torch.empty(B, L, c, device="cuda")
+    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, None, B, H, L, _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max().item() < 3e-4

@@ -32,6 +32,10 @@ SHAPES = [
     ("p1024_1024_256", 16, 1, 1024, 1024, 0, 256, 1, 1, 0, 0, 1),
     ("p256_256_256", 16, 1, 256, 256, 0, 256, 1, 1, 0, 0, 1),
     ("p256_1024_256", 16, 1, 256, 1024, 0, 256, 1, 1, 0, 0, 1),
+    # the GeGLU projection: planes in, GeGLU product out as planes (flag 2) / plain wide GEMM for comparison
+    ("pff1_1024_256_2048", 16, 1, 1024, 256, 0, 2048, 1, 1, 0, 0, 2),
+    ("pwide_1024_256_2048", 16, 1, 1024, 256, 0, 2048, 1, 1, 0, 0, 1),
+    ("pqkv_1024_256_768", 16, 1, 1024, 256, 0, 768, 1, 1, 0, 0, 3),
 ]
 
 
@@ -64,6 +68,11 @@ def main():
         a.bias, a.res, a.ld_res = bias.data_ptr(), res.data_ptr(), n
         a.out, a.ld_out, a.precision = out.data_ptr(), n, prec
         a.a_planes = int(planes)   # same bytes as fp32 [M][K]: the random bits are fine for timing
+        mode = rest[0] if rest else 0
+        if mode == 2:
+            a.geglu, a.ld_out, a.out_planes, a.res = 1, n // 2, out.data_ptr(), 0
+        if mode == 3:
+            a.qkv_planes, a.res = out.data_ptr(), 0
         st = torch.cuda.current_stream().cuda_stream
         for _ in range(3):
             _lib.check(lib.pf_conv2d(C.byref(a), st))
