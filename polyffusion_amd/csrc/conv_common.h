@@ -126,29 +126,47 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
             red[rl * pitch + wn * (WN / 2) + (lane & 31)] = (acc[fm][0][r] + bv) * gelu_erf_f(acc[fm][1][r] + bg);
           }
         }
-      } else {
+      } else {   // raw accumulators; bias / per-sample bias / residual are added row-wise below
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) {
-          const int cl = wn * WN + fn * 32 + (lane & 31), n = n0 + cl;
-          const bool nok = n < p.N;
-          const float cb = nok ? (p.bias ? p.bias[n] : 0.f) + (sb ? sb[n] : 0.f) : 0.f;
+          const int cl = wn * WN + fn * 32 + (lane & 31);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int rl = wm * WM + fm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float v = acc[fm][fn][r] + cb;
-            if (resp && nok && ox0 + rl < L) v += resp[((size_t)b * L + ox0 + rl) * p.ld_res + n];
-            red[rl * pitch + cl] = v;
+            red[rl * pitch + cl] = acc[fm][fn][r];
           }
         }
       }
     }
     __syncthreads();
+    // row-wise pass: a thread keeps one 8-column chunk (NT is a multiple of the chunks per row) and walks down the rows.
+    // All global loads (bias, per-sample bias, residual rows) are issued before the first LDS read so they overlap.
+    constexpr int NT = NWM * 128, ITER = TH * TW * (BN / 8) / NT;
     const int cpr = bno / 8;
-    for (int idx = tid; idx < TH * TW * cpr; idx += NWM * 128) {
-      const int rl = idx / cpr, col = (idx - rl * cpr) * 8;
-      if (ox0 + rl >= L || pq_n0 + col >= pq_n) continue;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(red + rl * pitch + col);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(red + rl * pitch + col + 4);
+    const int col = (tid % cpr) * 8, row0 = tid / cpr, rstep = NT / cpr;
+    const bool cok = pq_n0 + col < pq_n;
+    const int n = n0 + col;
+    f32x4 ba = {0.f, 0.f, 0.f, 0.f}, bc = ba;
+    if (!p.geglu && cok) {
+      if (p.bias) { ba += *reinterpret_cast<const f32x4*>(p.bias + n); bc += *reinterpret_cast<const f32x4*>(p.bias + n + 4); }
+      if (sb) { ba += *reinterpret_cast<const f32x4*>(sb + n); bc += *reinterpret_cast<const f32x4*>(sb + n + 4); }
+    }
+    f32x4 ra[ITER], rc[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int rl = row0 + it * rstep;
+      ra[it] = ba; rc[it] = bc;
+      if (resp && cok && rl < TH * TW && ox0 + rl < L) {
+        const float* rp = resp + ((size_t)b * L + ox0 + rl) * p.ld_res + n;
+        ra[it] += *reinterpret_cast<const f32x4*>(rp); rc[it] += *reinterpret_cast<const f32x4*>(rp + 4);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int rl = row0 + it * rstep;
+      if (!cok || rl >= TH * TW || ox0 + rl >= L) continue;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(red + rl * pitch + col) + ra[it];
+      const f32x4 c = *reinterpret_cast<const f32x4*>(red + rl * pitch + col + 4) + rc[it];
       bf16x8_t hi, lo;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -509,7 +509,6 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
     c.conv(a, PF_K_GEMM);
   }
   float* t0 = ta; float* t1 = tbuf; float* t2 = tc;
-  bool last_planes = false;
   for (size_t i = 0; i < L.tbs.size(); ++i) {
     const Layer::TB& t = L.tbs[i];
     // x = attn1(LN1(x)) + x
@@ -582,8 +581,6 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
     {
       pf_conv_args a = conv_base(ff, 4 * C, nullptr, 0, B, 1, hw, 1, c.w(t.ff2w), C, t2);
       a.bias = c.w(t.ff2b); a.res = t1; a.ld_res = C; a.a_planes = planes ? 1 : 0;
-      last_planes = planes && (i + 1 == L.tbs.size());
-      if (last_planes) a.out_planes = c.dry ? (void*)1 : (void*)t2;   // only proj_out reads it
       c.conv(a, PF_K_GEMM);
     }
     std::swap(t0, t2);
@@ -591,7 +588,7 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
   Tn ot;
   {
     pf_conv_args a = conv_base(t0, C, nullptr, 0, B, 1, hw, 1, c.w(L.pout_w), C, out);
-    a.bias = c.w(L.pout_b); a.res = x; a.ld_res = C; a.a_planes = last_planes ? 1 : 0;
+    a.bias = c.w(L.pout_b); a.res = x; a.ld_res = C;
     c.conv(a, PF_K_GEMM, &ot, true);
   }
   return ot;
