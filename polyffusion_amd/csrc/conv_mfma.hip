@@ -247,7 +247,7 @@ int conv_pick_tile(const pf_conv_args& a) {
     static const int force = getenv("PF_TILE") ? atoi(getenv("PF_TILE")) : -1;
     if (force >= 0 && !(force == 3 && (a.precision != PF_PREC_BF16X3 || a.ks != 3))) return force;
   }
-  if (npad % 128 == 0 && mt128 * (npad / 128) >= 512) return 0;
+  if (npad % 128 == 0 && mt128 * (npad / 128) >= (a.precision == PF_PREC_BF16X3 && a.ks == 3 ? 256 : 512)) return 0;   // bf16x3 3x3: the wide tile + split-K beats twice as many narrow tiles
   if (mt128 * (npad / 64) >= 512) return 1;
   return 2;
 }

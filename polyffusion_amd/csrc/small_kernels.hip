@@ -49,10 +49,67 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
   }
 }
 
+// Register-weight variant: a workgroup owns a 16x16 pixel tile, stages its 18x18xCIN input halo in LDS once, and every
+// thread keeps the 4 x CIN x 9 weights of ONE output-channel quad in registers while it walks the 16 pixels of a tile
+// column.  A pixel's Cout floats are written by 16 adjacent lanes as one contiguous NHWC run (16 bytes per lane).
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_in_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                          int H, int W) {
+  constexpr int K = CIN * 9, T = 16, TI = T + 2, COUT = 64;
+  __shared__ float sx[CIN][TI][TI + 1];
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int tilesx = (W + T - 1) / T, tilesy = (H + T - 1) / T;
+  const int tx = bid % tilesx; bid /= tilesx;
+  const int ty = bid % tilesy;
+  const int b = bid / tilesy;
+  for (int u = tid; u < CIN * TI * TI; u += 256) {
+    const int ci = u / (TI * TI), r = (u / TI) % TI, c = u % TI;
+    const int iy = ty * T + r - 1, ix = tx * T + c - 1;
+    sx[ci][r][c] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[((size_t)b * CIN + ci) * H * W + (size_t)iy * W + ix] : 0.f;
+  }
+  const int cq = tid & 15, px = tid >> 4;
+  float wr[4][K], bj[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bj[j] = bias[cq * 4 + j];
+#pragma unroll
+    for (int k = 0; k < K; ++k) wr[j][k] = w[(size_t)(cq * 4 + j) * K + k];
+  }
+  __syncthreads();
+  const int ox = tx * T + px;
+  if (ox >= W) return;
+#pragma unroll 4
+  for (int py = 0; py < T; ++py) {
+    const int oy = ty * T + py;
+    if (oy >= H) break;
+    float acc[4] = {bj[0], bj[1], bj[2], bj[3]};
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+          const float v = sx[ci][py + r][px + s2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(v, wr[j][ci * 9 + r * 3 + s2], acc[j]);   // order: ci, then tap
+        }
+    *reinterpret_cast<float4*>(out + (((size_t)b * H + oy) * W + ox) * COUT + cq * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
 int launch_conv_in(const float* x, const float* w, const float* bias, float* out, int batch, int cin, int cout, int h, int w_,
                    hipStream_t stream) {
   PF_REQUIRE(cout % 4 == 0 && (size_t)cout * cin * 9 * 4 <= 64 * 1024, "conv_in: unsupported channel counts %d->%d", cin, cout);
   const size_t total = (size_t)batch * h * w_ * (cout / 4);
+  if (cin <= 2 && cout == 64) {
+    const int grid = batch * cdiv(h, 16) * cdiv(w_, 16);
+    if (cin == 1) hipLaunchKernelGGL(conv_in_reg_kernel<1>, dim3(grid), dim3(256), 0, stream, x, w, bias, out, batch, h, w_);
+    else hipLaunchKernelGGL(conv_in_reg_kernel<2>, dim3(grid), dim3(256), 0, stream, x, w, bias, out, batch, h, w_);
+    PF_CHECK_HIP(hipGetLastError());
+    return PF_OK;
+  }
   const int grid = (int)min((size_t)4096, (total + 255) / 256);
   hipLaunchKernelGGL(conv_in_kernel, dim3(grid), dim3(256), (size_t)cout * cin * 9 * sizeof(float), stream, x, w, bias, out, batch,
                      cin, cout, h, w_);
