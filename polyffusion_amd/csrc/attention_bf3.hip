@@ -16,6 +16,13 @@
 
 namespace pf {
 
+#ifdef PF_TRACE
+__device__ unsigned long long g_trace_attn[4096];
+#define TRA() do { if (trace_on && tslot < 2040) { g_trace_attn[tslot++] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define TRA() do {} while (0)
+#endif
+
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct AttnP3 {
@@ -25,18 +32,26 @@ struct AttnP3 {
   float scale;
 };
 
-__global__ __launch_bounds__(256, 2) void attn_bf3_kernel(AttnP3 p) {
-  constexpr int DH = 64, KT = 64;
+// NWAVES waves x 32 queries per workgroup share every K / V^T tile; RING tile stages in LDS (32 KB each).
+// <4, 2>: 128 queries, two workgroups per CU.  <8, 4>: 256 queries, one workgroup per CU - half the tile traffic and half
+// the direct-to-LDS issue work per wave, three tiles of prefetch distance.
+template <int NWAVES, int RING>
+__global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_kernel(AttnP3 p) {
+  constexpr int DH = 64, KT = 64, NT = NWAVES * 64, NP = 2048 / NT;   // NP direct-to-LDS pieces per thread and tile
   constexpr int STAGE = 4 * KT * DH;          // bf16 elements per stage: K hi, K lo, V^T hi, V^T lo (8 KB each)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);   // [2 stages][4 arrays][64 rows][64]
+  __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);   // [RING stages][4 arrays][64 rows][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+#ifdef PF_TRACE
+  const bool trace_on = tid == 0 && qt == 1 && h == 1 && b == 1;
+  int tslot = 0;
+#endif
   const int g = lane >> 5;
   const int C = p.H * DH, L = p.L;
   const size_t MC = (size_t)p.B * L * C;
-  const int qi = qt * 128 + wave * 32 + (lane & 31);
+  const int qi = qt * (NWAVES * 32) + wave * 32 + (lane & 31);
 
   // Q fragments (B operand of S^T): lane (q, g) holds d = 16 s + 8 g .. +7 of its query, hi and lo
   bf16x8 qh[4], ql[4];
@@ -49,22 +64,23 @@ __global__ __launch_bounds__(256, 2) void attn_bf3_kernel(AttnP3 p) {
     }
   }
 
-  // direct-to-LDS tile loads: 2048 16-byte units per stage, 8 per thread; unit u -> array u/512, row (u%512)/8, slot u%8
-  const int urow = (tid >> 3), uslot = tid & 7;
+  // direct-to-LDS tile loads: 2048 16-byte units per stage, NP per thread; unit u = tid + j*NT -> array u/512 (K hi, K lo,
+  // V^T hi, V^T lo), row (u%512)/8, slot u%8
   const __bf16* kbase = p.planes + 2 * MC + (size_t)b * L * C + h * DH;           // + plane*MC + key*C + d
   const __bf16* vbase = p.planes + 4 * MC + ((size_t)b * p.H + h) * DH * L;       // + plane*MC + d*L + key
+  auto issue_piece = [&](int t, int stage, int j) {
+    const int u = tid + j * NT;
+    const int arr = u >> 9, row = (u & 511) >> 3;
+    const int src_slot = (u & 7) ^ (row & 7);     // swizzle on the SOURCE side; the LDS image stays lane-linear
+    const __bf16* gp = (arr < 2) ? kbase + (size_t)(arr & 1) * MC + (size_t)(t * KT + row) * C + src_slot * 8
+                                 : vbase + (size_t)(arr & 1) * MC + (size_t)row * L + t * KT + src_slot * 8;
+    __bf16* lp = sm + stage * STAGE + (j * NT + wave * 64) * 8;   // wave-uniform; the hardware adds lane*16 B
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                     (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+  };
   auto issue_tile = [&](int t, int stage) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int arr = j >> 1;                     // 0 K hi, 1 K lo, 2 V^T hi, 3 V^T lo
-      const int row = urow + 32 * (j & 1);
-      const int src_slot = uslot ^ (row & 7);     // swizzle on the SOURCE side; the LDS image stays lane-linear
-      const __bf16* gp = (arr < 2) ? kbase + (size_t)(arr & 1) * MC + (size_t)(t * KT + row) * C + src_slot * 8
-                                   : vbase + (size_t)(arr & 1) * MC + (size_t)row * L + t * KT + src_slot * 8;
-      __bf16* lp = sm + stage * STAGE + arr * (KT * DH) + (wave * 64 + (j & 1) * 256) * 8;   // wave-uniform; HW adds lane*16 B
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                       (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
-    }
+    for (int j = 0; j < NP; ++j) issue_piece(t, stage, j);
   };
 
   f32x16 oacc[2];
@@ -85,95 +101,122 @@ __global__ __launch_bounds__(256, 2) void attn_bf3_kernel(AttnP3 p) {
   constexpr int STAGE_B = STAGE * 2, ARR_B = KT * DH * 2;
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
-  // One tile = 16 "steps" of {two ds_read_b128 (hi, lo), three MFMAs}; the reads of step i+1 are issued before the MFMAs of
-  // step i and waited for with a counted lgkmcnt (inline asm reads - see conv_common.h), so the matrix pipe never waits
-  // for an LDS round trip.  One barrier per tile: it publishes tile t and frees the other stage for tile t+1.
+  // One tile = 4 K-step pairs of S^T = K.Q^T, the softmax, and 4 key blocks of O^T += V^T.P^T.  Each step issues the four
+  // ds_read_b128 (hi/lo of two fragments) of the NEXT step before its own six MFMAs, which alternate between two
+  // independent accumulators so the wave's in-order issue never stalls on an accumulator dependency; the next tile's eight
+  // direct-to-LDS loads are spread over the S steps and the hi/lo split of the next key block's probabilities is
+  // interleaved with the MFMAs of the current one.  LDS waits are counted by hand (inline-asm reads, conv_common.h).
+  // One barrier per tile: it publishes tile t and frees the other stage for tile t+1.
+  auto psplit = [&](const f32x16& sv, int half, bf16x8& ph, bf16x8& pl) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float v = sv[half * 8 + q];
+      const __bf16 hi = (__bf16)v;
+      ph[q] = hi;
+      pl[q] = (__bf16)(v - (float)hi);
+    }
+  };
   auto tile_body = [&](auto stc, int t) {
     constexpr int ST = decltype(stc)::value;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    constexpr int SB0 = ST * STAGE_B;
+    TRA();
+    // tile t has landed once only the RING-2 newer tiles of this thread are outstanding; the barrier publishes it and
+    // frees the stage of tile t-1, which is refilled with tile t+RING-1 during the S phase
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 2) * NP) : "memory");
+    TRA();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue_tile(min(t + 1, ntile - 1), ST ^ 1);
+    TRA();
+    const int tn = min(t + RING - 1, ntile - 1);
+    constexpr int STN = (ST + RING - 1) % RING;
 
-    // ---- S^T = K . Q^T : step i -> K-step pair sp = i >> 1, key fragment kf = i & 1 ----
+    // ---- S^T = K . Q^T ----
     f32x16 s[2];
 #pragma unroll
     for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kf][r] = 0.f;
-    bf16x8 fh[2], fl[2];
-    fh[0] = lds_read128<ST * STAGE_B>(faddr[0]);
-    fl[0] = lds_read128<ST * STAGE_B + ARR_B>(faddr[0]);
-    static_for<0, 8>([&](auto ic) {
-      constexpr int i = decltype(ic)::value, sp = i >> 1, kf = i & 1, b = i & 1;
+    bf16x8 fh[2][2], fl[2][2];   // [buffer][fragment]
+    fh[0][0] = lds_read128<SB0>(faddr[0]);          fl[0][0] = lds_read128<SB0 + ARR_B>(faddr[0]);
+    fh[0][1] = lds_read128<SB0 + 4096>(faddr[0]);   fl[0][1] = lds_read128<SB0 + ARR_B + 4096>(faddr[0]);
+    static_for<0, 4>([&](auto ic) {
+      constexpr int sp = decltype(ic)::value, b = sp & 1;
       SB();
-      if constexpr (i < 7) {
-        constexpr int sp1 = (i + 1) >> 1, kf1 = (i + 1) & 1;
-        fh[b ^ 1] = lds_read128<ST * STAGE_B + kf1 * 4096>(faddr[sp1]);
-        fl[b ^ 1] = lds_read128<ST * STAGE_B + ARR_B + kf1 * 4096>(faddr[sp1]);
+      if constexpr (sp < 3) {
+        fh[b ^ 1][0] = lds_read128<SB0>(faddr[sp + 1]);          fl[b ^ 1][0] = lds_read128<SB0 + ARR_B>(faddr[sp + 1]);
+        fh[b ^ 1][1] = lds_read128<SB0 + 4096>(faddr[sp + 1]);   fl[b ^ 1][1] = lds_read128<SB0 + ARR_B + 4096>(faddr[sp + 1]);
       } else {   // first V^T fragments, in flight across the softmax
-        fh[b ^ 1] = lds_read128<ST * STAGE_B + 2 * ARR_B>(faddr[0]);
-        fl[b ^ 1] = lds_read128<ST * STAGE_B + 3 * ARR_B>(faddr[0]);
+        fh[b ^ 1][0] = lds_read128<SB0 + 2 * ARR_B>(faddr[0]);          fl[b ^ 1][0] = lds_read128<SB0 + 3 * ARR_B>(faddr[0]);
+        fh[b ^ 1][1] = lds_read128<SB0 + 2 * ARR_B + 4096>(faddr[0]);   fl[b ^ 1][1] = lds_read128<SB0 + 3 * ARR_B + 4096>(faddr[0]);
       }
-      lgkm_wait<2>(); SB();
-      s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b], qh[sp], s[kf], 0, 0, 0);
-      s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], ql[sp], s[kf], 0, 0, 0);
-      s[kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], qh[sp], s[kf], 0, 0, 0);
+      if constexpr (NP == 8) { issue_piece(tn, STN, 2 * sp); issue_piece(tn, STN, 2 * sp + 1); }
+      else issue_piece(tn, STN, sp);
+      lgkm_wait<4>(); SB();
+      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b][0], qh[sp], s[0], 0, 0, 0);
+      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b][1], qh[sp], s[1], 0, 0, 0);
+      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][0], ql[sp], s[0], 0, 0, 0);
+      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][1], ql[sp], s[1], 0, 0, 0);
+      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][0], qh[sp], s[0], 0, 0, 0);
+      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][1], qh[sp], s[1], 0, 0, 0);
       SB();
     });
-    // ---- online softmax (lane holds 32 keys of its query, the partner lane^32 the other 32) ----
+    TRA();
+    // ---- online softmax in the exp2 domain (lane holds 32 keys of its query, the partner lane^32 the other 32).
+    // Whole-vector arithmetic lets the compiler use the packed fp32 ALU ops; the running maximum only moves - and the
+    // accumulators are only rescaled - when some query of the wave actually found a larger score in this tile.
+    const float c2 = p.scale * 1.44269504088896340736f;
     float mx = -INFINITY;
 #pragma unroll
-    for (int kf = 0; kf < 2; ++kf)
+    for (int kf = 0; kf < 2; ++kf) {
+      s[kf] = s[kf] * c2;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[kf][r] *= p.scale; mx = fmaxf(mx, s[kf][r]); }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kf][r]);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {   // wave-uniform
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int df = 0; df < 2; ++df) oacc[df] = oacc[df] * alpha;
+    }
     float psum = 0.f;
 #pragma unroll
-    for (int kf = 0; kf < 2; ++kf)
+    for (int kf = 0; kf < 2; ++kf) {
+      s[kf] = s[kf] - m_run;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { const float pv = __expf(s[kf][r] - m_new); s[kf][r] = pv; psum += pv; }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int df = 0; df < 2; ++df)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[df][r] *= alpha;
-
-    // ---- O^T += V^T . P^T : step j -> 16-key block kb = j >> 1, channel fragment df = j & 1; registers 8kb'..8kb'+7 of a
-    // score fragment are this lane's 8 keys of block kb.  Step 0's fragments sit in buffer 0 (loaded by S step 7). ----
-    bf16x8 ph, pl;
-    static_for<0, 8>([&](auto jc) {
-      constexpr int j = decltype(jc)::value, kb = j >> 1, df = j & 1, b = j & 1;
+      for (int r = 0; r < 16; ++r) { const float pv = __builtin_amdgcn_exp2f(s[kf][r]); s[kf][r] = pv; psum += pv; }
+    }
+    l_run += psum;
+    TRA();
+    // ---- O^T += V^T . P^T : key block kb (16 keys); registers 8kb'..8kb'+7 of a score fragment are this lane's 8 keys of
+    // block kb.  Block 0's V^T fragments sit in buffer 0 (loaded by S step 3: b ^ 1 == 0). ----
+    bf16x8 ph[2], pl[2];
+    psplit(s[0], 0, ph[0], pl[0]);
+    static_for<0, 4>([&](auto jc) {
+      constexpr int kb = decltype(jc)::value, b = kb & 1;
       SB();
-      if constexpr (j < 7) {
-        constexpr int kb1 = (j + 1) >> 1, df1 = (j + 1) & 1;
-        fh[b ^ 1] = lds_read128<ST * STAGE_B + 2 * ARR_B + df1 * 4096>(faddr[kb1]);
-        fl[b ^ 1] = lds_read128<ST * STAGE_B + 3 * ARR_B + df1 * 4096>(faddr[kb1]);
+      if constexpr (kb < 3) {
+        fh[b ^ 1][0] = lds_read128<SB0 + 2 * ARR_B>(faddr[kb + 1]);          fl[b ^ 1][0] = lds_read128<SB0 + 3 * ARR_B>(faddr[kb + 1]);
+        fh[b ^ 1][1] = lds_read128<SB0 + 2 * ARR_B + 4096>(faddr[kb + 1]);   fl[b ^ 1][1] = lds_read128<SB0 + 3 * ARR_B + 4096>(faddr[kb + 1]);
       }
-      if constexpr (df == 0) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float v = s[kb >> 1][(kb & 1) * 8 + q];
-          const __bf16 hi = (__bf16)v;
-          ph[q] = hi;
-          pl[q] = (__bf16)(v - (float)hi);
-        }
-      }
-      lgkm_wait<(j < 7) ? 2 : 0>(); SB();
-      oacc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b], ph, oacc[df], 0, 0, 0);
-      oacc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], pl, oacc[df], 0, 0, 0);
-      oacc[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b], ph, oacc[df], 0, 0, 0);
+      lgkm_wait<(kb < 3) ? 4 : 0>(); SB();
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b][0], ph[b], oacc[0], 0, 0, 0);
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b][1], ph[b], oacc[1], 0, 0, 0);
+      if constexpr (kb < 3) psplit(s[(kb + 1) >> 1], (kb + 1) & 1, ph[b ^ 1], pl[b ^ 1]);   // next block's split, in the MFMA shadow
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][0], pl[b], oacc[0], 0, 0, 0);
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][1], pl[b], oacc[1], 0, 0, 0);
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][0], ph[b], oacc[0], 0, 0, 0);
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][1], ph[b], oacc[1], 0, 0, 0);
       SB();
     });
   };
-  issue_tile(0, 0);
-  for (int t = 0; t < ntile; t += 2) {
-    tile_body(std::integral_constant<int, 0>{}, t);
-    tile_body(std::integral_constant<int, 1>{}, t + 1);
-  }
+  TRA();
+#pragma unroll
+  for (int d = 0; d < RING - 1; ++d) issue_tile(min(d, ntile - 1), d);
+  for (int t = 0; t < ntile; t += RING)   // ntile is a multiple of RING (launcher)
+    static_for<0, RING>([&](auto st) { tile_body(st, t + decltype(st)::value); });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail prefetch
 #undef SB
 
@@ -202,12 +245,28 @@ __global__ __launch_bounds__(256, 2) void attn_bf3_kernel(AttnP3 p) {
 int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, hipStream_t stream) {
   PF_REQUIRE(planes && (o || o_planes) && batch > 0 && n_heads > 0 && l > 0 && l % 128 == 0, "attention_bf3: L must be a positive multiple of 128");
   AttnP3 p{static_cast<const __bf16*>(planes), o, ldo, static_cast<__bf16*>(o_planes), batch, n_heads, l, 0.125f};
-  constexpr size_t lds = (size_t)2 * 4 * 64 * 64 * 2;
+  // 256-query workgroups when that still gives every CU one (and the tile count suits the 4-stage ring)
+  // Measured on MI355X (B=16, L=1024): the 8-wave form loses - its waves run S / softmax / PV in lockstep behind one barrier,
+  // so the matrix pipe idles during every softmax, while two independent 4-wave workgroups per CU drift apart and fill
+  // each other's gaps.  Kept for experiments (PF_ATTN_WIDE=1).
+  static const bool want_wide = getenv("PF_ATTN_WIDE") && atoi(getenv("PF_ATTN_WIDE")) != 0;
+  const bool wide = want_wide && l % 256 == 0 && (l / 256) * n_heads * batch >= 192;
   static bool done = false;
-  if (!done) { PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
-  hipLaunchKernelGGL(attn_bf3_kernel, dim3(l / 128, n_heads, batch), dim3(256), lds, stream, p);
+  if (!done) {
+    PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf3_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768));
+    PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf3_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+    done = true;
+  }
+  if (wide) hipLaunchKernelGGL((attn_bf3_kernel<8, 4>), dim3(l / 256, n_heads, batch), dim3(512), 4 * 32768, stream, p);
+  else hipLaunchKernelGGL((attn_bf3_kernel<4, 2>), dim3(l / 128, n_heads, batch), dim3(256), 2 * 32768, stream, p);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }
+
+#ifdef PF_TRACE
+extern "C" int pf_debug_trace_read_attn(unsigned long long* dst, int n) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace_attn), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace pf

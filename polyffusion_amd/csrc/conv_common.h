@@ -18,7 +18,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int OFF>
 __device__ __forceinline__ bf16x8 lds_read128(unsigned addr) {
   u32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  constexpr int HI = OFF & ~0xFFFF, LO = OFF & 0xFFFF;   // the instruction's offset field is 16 bits
+  if constexpr (HI != 0) addr += HI;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(LO));
   return __builtin_bit_cast(bf16x8, v);
 }
 template <int N>

@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Cycle-stamp timeline of one workgroup of the bf16x3 attention kernel (needs a PF_TRACE build)."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from polyffusion_amd import _lib
+lib = _lib.load()
+B, H, L = 16, 4, 1024
+c = H * 64
+planes = (torch.randn(B * L * 3 * c * 2, device="cuda") * 0.5).to(torch.bfloat16)
+out = torch.empty(B, L, c, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, None, B, H, L, st)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, None, B, H, L, st)
+e1.record(); torch.cuda.synchronize()
+print("kernel us", e0.elapsed_time(e1) * 100)
+buf = (C.c_ulonglong * 4096)()
+lib.pf_debug_trace_read_attn(buf, 4096)
+a = np.array(buf[:], dtype=np.int64); a = a[a > 0]
+d = np.diff(a)
+print("stamps", len(a), "total", a[-1] - a[0])
+body = d[1:]
+n = len(body) // 5 * 5
+t = body[:n].reshape(-1, 5)
+print("per tile [wait, barrier, S phase (+next tile's glds), softmax, PV + loop]")
+for r in t[:6]: print("   ", r.tolist(), int(r.sum()))
+print("mean", t.mean(0).round(0).tolist(), round(float(t.sum(1).mean())))
