@@ -174,6 +174,14 @@ typedef struct pf_conv_args {
   void* out_planes;                                          /* optional: write the result as bf16 hi/lo planes [M][ld_out] | [M][ld_out] instead of fp32 `out` */
   void* qkv_planes;                                          /* optional (ks=1, N = 3C, d_head 64): instead of `out`, write the fused q|k|v projection
                                                                 as bf16 hi/lo planes [qh|ql|kh|kl|vTh|vTl] (each B*L*C) for pf_attention_bf16x3 */
+  /* optional fused 1x1 projection of a second tensor, accumulated into the same output tile (the ResBlock's
+   * skip_connection conv folded into its second 3x3 conv, unet.py:262-277): out += skip_w . concat(skip_x0, skip_x1) + skip_bias.
+   * bf16x3, ks = 3, stride 1, no upsampling; skip_w is the bf16x3 packing of the [n][skip_c0+skip_c1] weight, channel
+   * counts multiples of 32. */
+  const float* skip_x0; int32_t skip_c0;
+  const float* skip_x1; int32_t skip_c1;
+  const void* skip_w;
+  const float* skip_bias;
 } pf_conv_args;
 /* scratch bytes a launch with these arguments would like for split-K (0 = the launch does not split) */
 size_t pf_conv_splitk_ws_bytes(const pf_conv_args* a);

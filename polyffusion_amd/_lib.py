@@ -50,6 +50,8 @@ class ConvArgs(C.Structure):
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t),
         ("a_planes", C.c_int32), ("out_planes", C.c_void_p),
         ("qkv_planes", C.c_void_p),
+        ("skip_x0", C.c_void_p), ("skip_c0", C.c_int32), ("skip_x1", C.c_void_p), ("skip_c1", C.c_int32),
+        ("skip_w", C.c_void_p), ("skip_bias", C.c_void_p),
     ]
 
 

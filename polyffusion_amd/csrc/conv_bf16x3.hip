@@ -31,7 +31,7 @@ __device__ unsigned long long g_trace[8192];
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM>
+template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM, bool SKIP>
 __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   constexpr int NT = NWM * 128;            // threads: NWM x 2 waves
   constexpr int BK = 32;
@@ -387,6 +387,97 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // drain the clamped tail prefetches before the workgroup retires
   }
 
+  if constexpr (SKIP) {
+    // ---- fused 1x1 projection of a second tensor into the same accumulators (the ResBlock skip conv): one extra K range
+    // over concat(sx0, sx1), no prologue, weights [K/8][plane][Npad][8].  Register-staged and double-buffered like the
+    // KS == 1 path, on the LDS the 3x3 loop has finished with; done by K-slice 0 only when the conv is split.
+    if (sidx == 0) {
+      constexpr int NA1 = BM * KQ / NT;          // float4 pieces per thread of a 32-channel slab of the tile's own pixels
+      static_assert(BM * KQ % NT == 0, "tile pixels must divide over the block");
+      __bf16* a1h = reinterpret_cast<__bf16*>(smem_raw);
+      __bf16* a1l = a1h + 2 * BM * PITCH;
+      __bf16* w1 = a1l + 2 * BM * PITCH;          // [2 bufs][4 k8][2 planes][BN][8]
+      int goff[NA1];
+#pragma unroll
+      for (int i = 0; i < NA1; ++i) {
+        const int pix = tid / KQ + i * PSTEP;
+        const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
+        goff[i] = (oy < p.Hout && ox < p.Wout) ? (b * p.Hout + oy) * p.Wout + ox : -1;
+      }
+      f32x4 r1[NA1];
+      u32x4 rw1[NW];
+      auto load1 = [&](int chunk) {
+        const int cg = chunk * BK;
+        const float* src; int cs, co;
+        if (cg < p.sc0) { src = p.sx0; cs = p.sc0; co = cg; } else { src = p.sx1; cs = p.sc1; co = cg - p.sc0; }
+#pragma unroll
+        for (int i = 0; i < NA1; ++i) {
+          if (goff[i] >= 0) r1[i] = *reinterpret_cast<const f32x4*>(src + co + (unsigned)(goff[i] * cs + c4 * 4));
+          else r1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          const int u = tid + j * NT;
+          const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
+          rw1[j] = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(p.sw) + ((size_t)((chunk * 4 + k8l) * 2 + plane) * p.Npad + n0 + n) * 8);
+        }
+      };
+      auto store1 = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA1; ++i) {
+          const bf16x4 hi = __builtin_convertvector(r1[i], bf16x4);
+          const bf16x4 lo = __builtin_convertvector(r1[i] - __builtin_convertvector(hi, f32x4), bf16x4);
+          const int o = (buf * BM + tid / KQ + i * PSTEP) * PITCH + c4 * 4;
+          *reinterpret_cast<bf16x4*>(a1h + o) = hi;
+          *reinterpret_cast<bf16x4*>(a1l + o) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) *reinterpret_cast<u32x4*>(w1 + buf * (TOTW * 8) + (tid + j * NT) * 8) = rw1[j];
+      };
+      int arow[FM];
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm) arow[fm] = (wm * WM + fm * 32 + (lane & 31)) * PITCH + 8 * (lane >> 5);
+      const int nch1 = (p.sc0 + p.sc1) / BK;
+      load1(0);
+      __syncthreads();                       // every wave is out of the 3x3 loop: its LDS images are dead
+      store1(0);
+      __syncthreads();
+      for (int chunk = 0; chunk < nch1; ++chunk) {
+        if (chunk + 1 < nch1) load1(chunk + 1);
+        const int ao = (chunk & 1) * BM * PITCH;
+        const __bf16* cW = w1 + (chunk & 1) * (TOTW * 8) + wbase;
+#pragma unroll
+        for (int s2 = 0; s2 < BK / 16; ++s2) {
+          bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm) {
+            ah[fm] = *reinterpret_cast<const bf16x8*>(a1h + ao + arow[fm] + s2 * 16);
+            al[fm] = *reinterpret_cast<const bf16x8*>(a1l + ao + arow[fm] + s2 * 16);
+          }
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn) {
+            bh[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s2) * BN + fn * 32) * 8);
+            bl[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s2 + 1) * BN + fn * 32) * 8);
+          }
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
+#pragma unroll
+          for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+        }
+        if (chunk + 1 < nch1) store1((chunk + 1) & 1);
+        __syncthreads();
+      }
+    }
+  }
+
   TR();
   if (p.partial) p.partial += (size_t)sidx * ((size_t)p.B * p.Hout * p.Wout) * p.N;
   conv_epilogue<TH, TW, BN, FM, FN, NWM>(p, acc, b, oy0, ox0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem_raw));
@@ -396,7 +487,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
 // out = sum_s partial[s] + bias + sbias[b] + res over a 64-row slab per workgroup; also emits the slab's per-channel
 // (sum, sumsq) as one statistics tile.  Deterministic (fixed summation order).
 __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __restrict__ part, int S, int M, int N, int hw,
-                                                            const float* __restrict__ bias, const float* __restrict__ sbias, int ld_sb,
+                                                            const float* __restrict__ bias, const float* __restrict__ bias2,
+                                                            const float* __restrict__ sbias, int ld_sb,
                                                             const float* __restrict__ res, int ld_res, float* __restrict__ out,
                                                             int ld_out, float* __restrict__ stats) {
   __shared__ float red[16][64][2];
@@ -407,7 +499,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
     const int n = blockIdx.y * 64 + c;
     float s1 = 0.f, s2 = 0.f;
     if (n < N) {
-      const float cb = (bias ? bias[n] : 0.f) + (sbias ? sbias[(size_t)b * ld_sb + n] : 0.f);
+      const float cb = (bias ? bias[n] : 0.f) + (bias2 ? bias2[n] : 0.f) + (sbias ? sbias[(size_t)b * ld_sb + n] : 0.f);
       for (int i = 0; i < 4; ++i) {
         const size_t m = row0 + rg + 16 * i;
         float v = cb;
@@ -432,17 +524,19 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
   }
 }
 
-template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM = 2>
+template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM = 2, bool SKIP = false>
 static int launch3_cfg(ConvP& p, hipStream_t stream) {
   constexpr int THIN = (TH - 1) * STRIDE + KS, TWIN = (TW - 1) * STRIDE + KS;
   constexpr int NABUF = (KS == 1) ? 2 : 1;
   constexpr int WRING = (KS == 1) ? 2 : 3;
-  constexpr size_t lds = (size_t)(2 * NABUF * THIN * TWIN * 40 + WRING * 8 * BN * 8) * 2;
+  constexpr size_t lds_main = (size_t)(2 * NABUF * THIN * TWIN * 40 + WRING * 8 * BN * 8) * 2;
+  constexpr size_t lds_skip = SKIP ? (size_t)(2 * 2 * TH * TW * 40 + 2 * 8 * BN * 8) * 2 : 0;   // the fused 1x1 phase's double buffers
+  constexpr size_t lds = lds_main > lds_skip ? lds_main : lds_skip;
   static_assert(lds <= 160 * 1024, "LDS budget");
   p.tiles_x = cdiv(p.Wout, TW);
   p.tiles_y = cdiv(p.Hout, TH);
   p.nt = cdiv(p.Npad, BN);
-  auto kern = conv_bf3_kernel<KS, STRIDE, UPS, TH, TW, BN, PRO, NWM>;
+  auto kern = conv_bf3_kernel<KS, STRIDE, UPS, TH, TW, BN, PRO, NWM, SKIP>;
   static bool attr_done = false;
   if (!attr_done) {
     PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -463,6 +557,13 @@ static int dispatch_tile3(ConvP& p, int tile, hipStream_t s) {
   } else if constexpr (STRIDE == 2) {
     return launch3_cfg<3, 2, false, 4, 16, 64, PRO>(p, s);
   } else {
+    if constexpr (!UPS && PRO == 1) {
+      if (p.sw) {   // fused skip projection: only the ResBlock second-conv configurations are instantiated
+        if (tile == 0) return launch3_cfg<3, 1, false, 8, 16, 128, 1, 2, true>(p, s);
+        if (tile == 1) return launch3_cfg<3, 1, false, 8, 16, 64, 1, 2, true>(p, s);
+        return launch3_cfg<3, 1, false, 4, 16, 64, 1, 2, true>(p, s);
+      }
+    }
     if (tile == 3) return launch3_cfg<3, 1, UPS, 16, 16, 64, PRO, 4>(p, s);
     if (tile == 0) return launch3_cfg<3, 1, UPS, 8, 16, 128, PRO>(p, s);
     if (tile == 1) return launch3_cfg<3, 1, UPS, 8, 16, 64, PRO>(p, s);
@@ -473,6 +574,7 @@ static int dispatch_tile3(ConvP& p, int tile, hipStream_t s) {
 // same argument validation as launch_conv (done by the caller); w points to the bf16x3 packing
 int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   ConvP p;
+  memset(&p, 0, sizeof p);
   p.x0 = a.x0; p.x1 = a.x1; p.c0 = a.c0; p.c1 = a.c1;
   p.B = a.batch; p.Hin = a.hin; p.Win = a.win;
   p.Hout = a.hin; p.Wout = a.win;
@@ -485,6 +587,7 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   p.ksplit = conv_ksplit(a);
   p.partial = p.ksplit > 1 ? static_cast<float*>(a.splitk_ws) : nullptr;
   p.qkv = a.qkv_planes; p.out_planes = a.out_planes;
+  p.sx0 = a.skip_x0; p.sc0 = a.skip_c0; p.sx1 = a.skip_x1; p.sc1 = a.skip_c1; p.sw = a.skip_w; p.bias2 = a.skip_w ? a.skip_bias : nullptr;
   const int tile = conv_pick_tile(a);
   if (a.ks == 1) {
     switch (a.prologue) {
@@ -498,7 +601,7 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   if (rc != PF_OK || p.ksplit == 1) return rc;
   const int M = p.B * p.Hout * p.Wout;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M / 64, cdiv(p.N, 64)), dim3(1024), 0, stream, static_cast<const float*>(a.splitk_ws), p.ksplit, M, p.N,
-                     p.Hout * p.Wout, p.bias, p.sbias, p.ld_sbias, p.res, p.ld_res, p.out, p.ld_out, p.stats);
+                     p.Hout * p.Wout, p.bias, p.bias2, p.sbias, p.ld_sbias, p.res, p.ld_res, p.out, p.ld_out, p.stats);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }

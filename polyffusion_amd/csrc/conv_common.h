@@ -41,6 +41,8 @@ struct ConvP {
   float* out; int ld_out;
   float* stats;   // optional [B][tiles][N][2]: per-tile, per-channel (sum, sum of squares) of the stored outputs
   int tiles_x, tiles_y, nt;
+  const float* sx0; const float* sx1; int sc0, sc1;   // fused 1x1 projection of a second tensor (ResBlock skip conv)
+  const void* sw; const float* bias2;
   void* out_planes;             // result as bf16 hi/lo planes [M][ld_out] | [M][ld_out] instead of fp32 (consumer: gemm_planes_bf3.hip)
   void* qkv;                    // fused q|k|v projection written as bf16 hi/lo planes for attention_bf3.hip (d_head 64)
   int ksplit; float* partial;   // split-K: raw accumulators to partial[split][M][N]; bias/residual/statistics happen in the reduce kernel
@@ -105,7 +107,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
       pq_ld = C; pq_n0 = n0 - which * C; pq_n = C;
     }
   }
-  if (pq) {
+  if constexpr (TH == 1) if (pq) {   // linear layers only: keeps this path's registers out of the 3x3 kernels' budget
     const float* sb = (p.sbias && !p.qkv) ? p.sbias + (size_t)b * p.ld_sbias : nullptr;
     const float* resp = p.qkv ? nullptr : p.res;
     // hi/lo plane output (linear layers only, TH == 1): the finished tile is transposed through LDS as fp32 so that the
@@ -181,7 +183,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
     }
     return;
   }
-  if (p.qkv) {
+  if constexpr (TH == 1) if (p.qkv) {
     // q|k|v planes for the bf16x3 attention: Q,K [token][C] and V^T [head][d][token] (middle token quads of every
     // 16-token block swapped, see attention_bf3.hip), each as a bf16 hi plane and a bf16 lo = bf16(x - hi) plane.
     typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -247,13 +249,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn) {
       ncol[fn] = n0 + wn * WN + fn * 32 + (lane & 31);
-      cb[fn] = (p.bias ? p.bias[ncol[fn]] : 0.f) + (sb ? sb[ncol[fn]] : 0.f);
+      cb[fn] = (p.bias ? p.bias[ncol[fn]] : 0.f) + (sb ? sb[ncol[fn]] : 0.f) + (p.bias2 ? p.bias2[ncol[fn]] : 0.f);
     }
-    // phase 1: all residual loads back to back (out may alias nothing here, but the compiler cannot know: keeping the
-    // loads ahead of every store lets them pipeline instead of serialising load -> add -> store per element)
-    if (p.res) {
+    // per 32-row fragment: all residual loads back to back, then the adds and stores (out may alias nothing here, but the
+    // compiler cannot know: keeping a fragment's loads ahead of its stores lets them pipeline instead of serialising
+    // load -> add -> store per element).  One fragment at a time bounds the in-flight temporaries to 16*FN registers - the
+    // epilogue must not need more VGPRs than the main loop, or it costs the whole kernel a wave of occupancy.
 #pragma unroll
-      for (int fm = 0; fm < FM; ++fm)
+    for (int fm = 0; fm < FM; ++fm) {
+      if (p.res) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -262,9 +266,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
 #pragma unroll
           for (int fn = 0; fn < FN; ++fn) acc[fm][fn][r] += p.res[m * p.ld_res + ncol[fn]];
         }
-    }
-#pragma unroll
-    for (int fm = 0; fm < FM; ++fm) {
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -277,6 +279,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
           ssum[fn] += v; ssq[fn] += v * v;
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else {
 #pragma unroll
@@ -306,6 +309,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
               float v = acc[fm][fn][r];
               if (p.bias) v += p.bias[n];
               if (sb) v += sb[n];
+              if (p.bias2) v += p.bias2[n];
               if (p.res) v += p.res[m * p.ld_res + n];
               store_out(p, m * p.ld_out + n, v);
               ssum[fn] += v; ssq[fn] += v * v;

@@ -336,6 +336,9 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
              "conv: qkv planes need ks=1, N = 3*heads*64 and L %% 16 == 0");
 
   PF_REQUIRE(a.precision == PF_PREC_F32 || a.precision == PF_PREC_BF16X3, "conv: bad precision %d", a.precision);
+  PF_REQUIRE(!a.skip_w || (a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.stride == 1 && !a.ups && a.skip_x0 && a.skip_c0 > 0 &&
+                           a.skip_c0 % 32 == 0 && a.skip_c1 % 32 == 0 && (a.skip_c1 == 0 || a.skip_x1) && !a.geglu),
+             "conv: fused skip projection needs bf16x3, ks=3, stride 1, channel counts multiples of 32");
   PF_REQUIRE(!a.out_planes || (a.precision == PF_PREC_BF16X3 && a.ks == 1 && !a.stats_out && a.ld_out % 8 == 0 &&
                                (a.geglu ? a.n / 2 : a.n) % 8 == 0),
              "conv: out_planes needs bf16x3, ks=1, no statistics, ld_out and n multiples of 8");
@@ -345,6 +348,7 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
   if (a.precision == PF_PREC_BF16X3) return launch_conv_bf3(a, stream);
 
   ConvP p;
+  memset(&p, 0, sizeof p);
   p.x0 = a.x0; p.x1 = a.x1; p.c0 = a.c0; p.c1 = a.c1;
   p.B = a.batch; p.Hin = a.hin; p.Win = a.win;
   p.Hout = a.hin; p.Wout = a.win;

@@ -473,7 +473,10 @@ static Tn run_res(Ctx& c, const Layer& L, const Tn& x0, const Tn& x1, int H, int
   }
   c.gn(ht, Tn{}, hw, 1e-5f, L.gn2_g, L.gn2_b, sc2, sh2);
   const float* res = x0.d;
-  if (ci != co) {
+  // bf16x3: the 1x1 skip_connection conv is folded into the second 3x3 conv as one more K range (no round trip of the
+  // projected tensor through HBM, one launch less)
+  const bool fuse_skip = ci != co && c.u->precision == PF_PREC_BF16X3 && x0.c % 32 == 0 && x1.c % 32 == 0 && co % 32 == 0;
+  if (ci != co && !fuse_skip) {
     float* sk = c.talloc((size_t)B * hw * co);
     pf_conv_args a = conv_base(x0.d, x0.c, x1.d, x1.c, B, 1, hw, 1, c.w(L.wskip), co, sk);
     a.bias = c.w(L.bskip);
@@ -483,7 +486,14 @@ static Tn run_res(Ctx& c, const Layer& L, const Tn& x0, const Tn& x1, int H, int
   Tn ot;
   {
     pf_conv_args a = conv_base(h, co, nullptr, 0, B, H, W_, 3, c.w(L.w2), co, out);
-    a.prologue = 1; a.sc = sc2; a.sh = sh2; a.bias = c.w(L.b2); a.res = res; a.ld_res = co;
+    a.prologue = 1; a.sc = sc2; a.sh = sh2; a.bias = c.w(L.b2);
+    if (fuse_skip) {
+      a.skip_x0 = x0.d; a.skip_c0 = x0.c; a.skip_x1 = x1.d; a.skip_c1 = x1.c;
+      a.skip_w = c.dry ? (const void*)1 : (const void*)(c.w(L.wskip) + (size_t)ci * ((co + 63) / 64 * 64));   // its bf16x3 packing
+      a.skip_bias = c.w(L.bskip);
+    } else {
+      a.res = res; a.ld_res = co;
+    }
     c.conv(a, PF_K_CONV3, &ot, true);
   }
   return ot;

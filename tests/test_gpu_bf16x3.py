@@ -286,3 +286,33 @@ def test_ln_planes_feeds_the_projection(lib, B, L, H):
     _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, None, B, H, L, _lib.current_stream()))
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max().item() < 3e-4
+
+
+@pytest.mark.parametrize("B,H,W,ch,c0,c1,cout", [(2, 32, 32, 128, 64, 64, 128), (1, 16, 16, 256, 256, 256, 256), (16, 16, 16, 256, 256, 256, 256),
+                                                  (3, 12, 20, 64, 96, 0, 64), (2, 64, 64, 64, 128, 64, 64)])
+def test_fused_skip_projection(lib, B, H, W, ch, c0, c1, cout):
+    """ResBlock tail in one launch: conv3x3(SiLU(GN(h))) + b2 + per-sample bias + skip_w . concat(x0, x1) + skip_b."""
+    cx = c0 + c1
+    hsrc = rnd((B, ch, H, W), 121) * 1.2 + 0.1
+    x = rnd((B, cx, H, W), 122)
+    w, bias = rnd((cout, ch, 3, 3), 123, (1.0 / (ch * 9)) ** 0.5), rnd((cout,), 124, 0.1)
+    ws, bs = rnd((cout, cx), 125, cx ** -0.5), rnd((cout,), 126, 0.1)
+    gamma, beta = 1 + 0.1 * rnd((ch,), 127), 0.1 * rnd((ch,), 128)
+    ref = F.conv2d(F.silu(F.group_norm(hsrc, 32, gamma, beta, eps=1e-5)), w, bias, padding=1) + F.conv2d(x, ws[:, :, None, None], bs)
+    hd = dev(nhwc(hsrc))
+    x0 = dev(nhwc(x[:, :c0]))
+    x1 = dev(nhwc(x[:, c0:])) if c1 else None
+    sc, sh = gn_scale_shift(lib, hd, None, dev(gamma), dev(beta), 1e-5)
+    out = torch.empty(B, H, W, cout, device="cuda")
+    ws_bytes = 0
+    kw = dict(x0=hd, c0=ch, batch=B, hin=H, win=W, ks=3, stride=1, ups=0, w=pack3(lib, w), n=cout, prologue=1, sc=sc, sh=sh,
+              bias=dev(bias), out=out, ld_out=cout, precision=1, skip_x0=x0, skip_c0=c0, skip_x1=x1, skip_c1=c1,
+              skip_w=pack3(lib, ws), skip_bias=dev(bs))
+    a = _lib.ConvArgs()
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+    ws_bytes = lib.pf_conv_splitk_ws_bytes(C.byref(a))
+    scratch = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device="cuda")
+    run_conv(lib, splitk_ws=scratch, splitk_ws_bytes=ws_bytes, **{k: v for k, v in kw.items() if v is not None})
+    err = (out.cpu() - nhwc(ref)).abs().max().item()
+    assert err < TOL_OP, err
