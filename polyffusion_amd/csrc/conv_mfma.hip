@@ -266,9 +266,13 @@ static int ksplit_wanted(const pf_conv_args& a) {
   conv_tile_shape(a, conv_pick_tile(a), &th, &tw);
   const int blocks = a.batch * cdiv(hout, th) * cdiv(wout, tw) * cdiv((a.n + 63) / 64 * 64, 64);
   const int nchunk = (a.c0 + a.c1) / 32;
-  if (blocks >= 512) return 1;
+  {  // experiment hook
+    static const int force = getenv("PF_KSPLIT") ? atoi(getenv("PF_KSPLIT")) : 0;
+    if (force > 0) return (nchunk % force == 0) ? force : 1;
+  }
+  if (blocks >= 256) return 1;   // one workgroup per CU already: measured, splitting further only adds the reduce pass
   int s = 1;
-  while (s < 4 && blocks * s * 2 <= 1536 && nchunk % (s * 2) == 0) s *= 2;
+  while (s < 4 && blocks * s * 2 <= 1024 && nchunk % (s * 2) == 0) s *= 2;
   return s;
 }
 size_t conv_splitk_ws_bytes(const pf_conv_args& a) {
@@ -312,7 +316,8 @@ double conv_flops(const pf_conv_args& a) {
     if (a.ups) { hout *= 2; wout *= 2; }
     if (a.stride == 2) { hout = (hout - 1) / 2 + 1; wout = (wout - 1) / 2 + 1; }
   }
-  return 2.0 * a.batch * hout * wout * (double)a.n * cin * a.ks * a.ks;
+  const double skip = a.skip_w ? (double)(a.skip_c0 + a.skip_c1) : 0.0;   // fused 1x1 projection of a second tensor
+  return 2.0 * a.batch * hout * wout * (double)a.n * (cin * a.ks * a.ks + skip);
 }
 
 int launch_conv(const pf_conv_args& a, hipStream_t stream) {

@@ -133,7 +133,7 @@ def test_small_unet_bf16x3_vs_reference_golden(golden):
     assert np.abs(m(x, t, torch.from_numpy(g["cond4"]).cuda()).cpu().numpy() - g["out4"]).max() < 5e-4
 
 
-@pytest.mark.parametrize("B,H,W,c0,c1,cout", [(2, 16, 16, 256, 256, 256), (1, 8, 8, 64, 0, 64), (16, 16, 16, 256, 0, 256)])
+@pytest.mark.parametrize("B,H,W,c0,c1,cout", [(2, 16, 16, 256, 256, 256), (1, 8, 8, 64, 0, 64), (4, 16, 16, 256, 0, 256)])
 def test_split_k_small_m_layers(lib, B, H, W, c0, c1, cout):
     """Small-M 3x3 layers split K over workgroups; the reduce kernel applies bias/sbias/residual and emits the statistics."""
     cin = c0 + c1
