@@ -169,7 +169,7 @@ def main():
         "path_tflops": round(F_MIN_PER_SAMPLE_EVAL * BATCH * world * args.steps / elapsed / 1e12, 3),
         "path_frac_of_f32_mfma_peak": round(F_MIN_PER_SAMPLE_EVAL * BATCH * args.steps / elapsed / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
         "precision_note": ("dense contractions on the bf16 matrix pipe as an error-compensated split (3 MFMAs per product, fp32 accumulate); "
-                           "UNet max-abs-diff vs the reference 4.7e-5 (contract 1e-3)") if args.precision == "bf16x3"
+                           "UNet max-abs-diff vs the reference 5.2e-5 (contract 1e-3)") if args.precision == "bf16x3"
         else "dense contractions on the fp32 matrix pipe (exact fp32 FMA chains)",
     }
 
