@@ -112,6 +112,13 @@ int pf_ddim_step(const float* x, const float* eps, const float* noise, const flo
  * elem_offset = index of out[0] in the global (unsharded) tensor. */
 int pf_randn(float* out, size_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, void* stream);
 
+/* ---- output step: generated onset/sustain image -> note durations ----
+ * Replaces the triple Python loop of utils.py:240-269 (prmat2c_to_prmat) and the note extraction of
+ * utils.py:433-476 (prmat2c_to_midi_file): dur[n][t][key] = length in steps of the note that starts at (t, key), 0 where no
+ * onset.  prmat2c is [n][2][steps][128] fp32 on the device (channel 0 onset, 1 sustain), dur is [n][steps][128] int32.
+ * Rounding is the reference's int(round(v)) > 0 (== v > 0.5); custom_round != 0 selects utils.py:395-399 for the onset. */
+int pf_prmat2c_durations(const float* prmat2c, int n, int steps, int custom_round, int32_t* dur, void* stream);
+
 /* ---- condition encoders (replace RnnEncoder.forward dl_modules/chord_enc.py:15-22 and
  *      TextureEncoder.forward dl_modules/txt_enc.py:23-35; only the Normal's mean is produced) */
 typedef struct pf_encoder pf_encoder;

@@ -69,6 +69,7 @@ int launch_time_embed(const int64_t* t, const float* w0, const float* b0, const 
                       float* out_silu, int batch, int channels, int d_t, hipStream_t stream);
 // y[b][n] = sum_k W[n][k] * x[b][k] + bias[n]   (row-major W [N][K]; one wave per output)
 // grouped form: output n reads x + (n / n_per_group) * x_group_stride (block-diagonal W); n_per_group <= 0 disables
+int launch_prmat2c_durations(const float* x, int n, int steps, int custom_round, int32_t* dur, hipStream_t stream);
 int launch_matvec(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int batch, int n, int k,
                   hipStream_t stream, int n_per_group = 0, int x_group_stride = 0);
 

@@ -193,6 +193,34 @@ int launch_conv_out(const float* x, const float* sc, const float* sh, const floa
   return PF_OK;
 }
 
+// ------------------------------------------------------------------ output step: onset/sustain image -> note durations
+// utils.py:240-269 / 433-476 of the reference: a note starts where round(onset) > 0 and lasts while round(sustain) > 0 on
+// the following steps of the same key.  Python's round is half-to-even on these float32 values, so the predicate is
+// exactly v > 0.5 (custom_round: 0.95 < v < 1.05, onset only).  One thread per (image, key) column walks its S steps
+// backwards keeping the length of the sustain run that starts at the next step: a single coalesced pass over the image
+// (lanes = consecutive keys), 4 B read per input element, 4 B written per output element.
+__global__ __launch_bounds__(128) void prmat2c_durations_kernel(const float* __restrict__ x, int S, int custom_round,
+                                                                int32_t* __restrict__ dur) {
+  const int n = blockIdx.x, key = threadIdx.x;
+  const float* on = x + ((size_t)n * 2 + 0) * S * 128 + key;
+  const float* su = x + ((size_t)n * 2 + 1) * S * 128 + key;
+  int32_t* d = dur + (size_t)n * S * 128 + key;
+  int run = 0;                                   // sustain run starting at step t+1
+  for (int t = S - 1; t >= 0; --t) {
+    const float o = on[(size_t)t * 128], sv = su[(size_t)t * 128];
+    const bool is_on = custom_round ? (o > 0.95f && o < 1.05f) : (o > 0.5f);
+    d[(size_t)t * 128] = is_on ? 1 + run : 0;
+    run = (sv > 0.5f) ? run + 1 : 0;
+  }
+}
+
+int launch_prmat2c_durations(const float* x, int n, int steps, int custom_round, int32_t* dur, hipStream_t stream) {
+  PF_REQUIRE(x && dur && n > 0 && steps > 0, "prmat2c_durations: bad arguments");
+  hipLaunchKernelGGL(prmat2c_durations_kernel, dim3(n), dim3(128), 0, stream, x, steps, custom_round, dur);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
 // ------------------------------------------------------------------ timestep embedding MLP
 // out[b][:] = silu( W2 . silu(W0 . [cos(t f) | sin(t f)] + b0) + b2 )   (the SiLU of emb_layers is folded in)
 __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restrict__ t, const float* __restrict__ w0,

@@ -860,6 +860,9 @@ int pf_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batc
                       void* stream) {
   return launch_gn_scale_shift(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, scale, shift, scratch, scratch_bytes, (hipStream_t)stream);
 }
+int pf_prmat2c_durations(const float* prmat2c, int n, int steps, int custom_round, int32_t* dur, void* stream) {
+  return launch_prmat2c_durations(prmat2c, n, steps, custom_round, dur, (hipStream_t)stream);
+}
 int pf_ln_planes(const float* x, int rows, int c, float eps, const float* gamma, const float* beta, void* planes, void* stream) {
   return launch_ln_planes(x, rows, c, eps, gamma, beta, planes, (hipStream_t)stream);
 }

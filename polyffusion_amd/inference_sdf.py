@@ -8,9 +8,9 @@ autoregressive 4-bar inpainting schedule (:202-303), ``get_autoreg_data`` (:121-
 ``dummy_cond_input`` (:60-72) and ``get_mask`` (:132-193).
 
 Not rebuilt (out of the hot-path scope): dataset / MIDI readers, chord
-extraction, MIDI writers, Polydis comparison.  Conditions therefore come from ``--cond_npz`` (arrays
+extraction, Polydis comparison.  Conditions therefore come from ``--cond_npz`` (arrays
 ``chord`` [B,32,36] and/or ``prmat`` [B,128,128], optional ``prmat2c`` for inpainting) or from the
-seeded synthetic generator (``--synthetic``); the result is written as ``.npy`` ([B,2,128,128] piano
+seeded synthetic generator (``--synthetic``); the result is written as ``.mid`` (polyffusion_amd.midi) and ``.npy`` ([B,2,128,128] piano
 roll, or [2B,2,64,128] half-segments for ``--autoreg``).  ``--synthetic_weights`` replaces the
 checkpoint by the deterministic weight generator (no trained weights ship with the reference).
 """
@@ -25,7 +25,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import synth
+from . import midi, synth
 from .model_sdf import ChordEncoder, Polyffusion_SDF, TextureEncoder
 from .params import Params, find_params, load_params, preset
 from .sampler import DDIMSampler, DiffusionSampler, SDFSampler
@@ -179,7 +179,9 @@ class Experiments:
         gen = self.predict(cond, cond_mid, uncond_scale, autoreg, cond_concat=cond_concat)
         if not no_output:
             os.makedirs(output_dir, exist_ok=True)
-            np.save(os.path.join(output_dir, self._stamp(uncond_scale, autoreg) + ".npy"), gen.cpu().numpy())
+            stamp = os.path.join(output_dir, self._stamp(uncond_scale, autoreg))
+            np.save(stamp + ".npy", gen.cpu().numpy())
+            midi.prmat2c_to_midi_file(gen, stamp + ".mid")            # ref:inference_sdf.py:335-338
         return gen
 
     def inpaint(self, orig, inpaint_type, cond, cond_mid=None, autoreg=False, orig_noise=None, uncond_scale=1.0,
@@ -188,8 +190,9 @@ class Experiments:
         gen = self.predict(cond, cond_mid, uncond_scale, autoreg, orig, mask, cond_concat=cond_concat, noise=orig_noise)
         if not no_output:
             os.makedirs(output_dir, exist_ok=True)
-            np.save(os.path.join(output_dir, self._stamp(uncond_scale, autoreg, f"_inp{self.repaint_n}_{inpaint_type}") + ".npy"),
-                    gen.cpu().numpy())
+            stamp = os.path.join(output_dir, self._stamp(uncond_scale, autoreg, f"_inp{self.repaint_n}_{inpaint_type}"))
+            np.save(stamp + ".npy", gen.cpu().numpy())
+            midi.prmat2c_to_midi_file(gen, stamp + ".mid", inp_mask=mask)   # ref:inference_sdf.py:385-389: generated cells on their own track
         return gen
 
 

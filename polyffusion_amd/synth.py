@@ -31,3 +31,17 @@ def prmat(batch: int, seed: int, steps: int = 128, pitches: int = 128) -> np.nda
     on = rng.random((batch, steps, pitches)) < 0.02
     dur = rng.integers(1, 17, (batch, steps, pitches))
     return (on * dur).astype(np.float32)
+
+
+def prmat2c_image(seed: int, n: int, steps: int = 128) -> np.ndarray:
+    """A generated-sample-like ``[n, 2, steps, 128]`` onset/sustain image for the output step (notes / MIDI): sparse onsets,
+    sustain runs, Gaussian jitter, and a sprinkle of the exact values the reference's rounding rules hinge on."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = np.zeros((n, 2, steps, 128), dtype=np.float32)
+    x[:, 0] = (rng.random((n, steps, 128)) < 0.03) * (0.6 + 0.8 * rng.random((n, steps, 128)))
+    x[:, 1] = (rng.random((n, steps, 128)) < 0.35) * (0.3 + 0.9 * rng.random((n, steps, 128)))
+    x += 0.05 * rng.standard_normal(x.shape).astype(np.float32)
+    flat = x.reshape(-1)
+    idx = rng.choice(flat.size, 600, replace=False)
+    flat[idx] = rng.choice(np.array([0.5, 1.5, -0.5, 0.95, 1.05, 1.0, 0.50000006, 0.49999997], dtype=np.float32), 600)
+    return x

@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""tests/golden/notes.npz: the reference's OUTPUT step on seeded images (build container only).
+
+Runs the REAL ``prmat2c_to_prmat`` and ``prmat2c_to_midi_file`` of /root/reference/polyffusion/utils.py.  pretty_midi is
+not installed, so the module is replaced by a RECORDING stand-in whose Note/Instrument/PrettyMIDI objects only collect
+what the reference hands them; the arrays written here are those collected values (pitch, start, end, velocity,
+instrument index), never reference source.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/polyffusion"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+from polyffusion_amd import synth  # noqa: E402
+
+
+def import_utils():
+    if not os.path.isdir(REF):
+        raise SystemExit("needs the reference mounted at /root/reference")
+    os.chdir(tempfile.mkdtemp(prefix="pf_golden_"))
+
+    def stub(name, **kw):
+        m = types.ModuleType(name)
+        m.__dict__.update(kw)
+        sys.modules[name] = m
+        return m
+
+    class Note:
+        def __init__(self, velocity, pitch, start, end):
+            self.velocity, self.pitch, self.start, self.end = velocity, pitch, start, end
+
+    class Instrument:
+        def __init__(self, program):
+            self.program, self.notes = program, []
+
+    class Lyric:
+        def __init__(self, text, time):
+            self.text, self.time = text, time
+
+    class PrettyMIDI:
+        last = None
+
+        def __init__(self):
+            self.instruments, self.lyrics = [], []
+            PrettyMIDI.last = self
+
+        def write(self, path):
+            self.path = path
+
+    stub("pretty_midi", Note=Note, Instrument=Instrument, Lyric=Lyric, PrettyMIDI=PrettyMIDI,
+         instrument_name_to_program=lambda name: {"Acoustic Grand Piano": 0}[name])
+    tv = stub("torchvision")
+    tv.models = stub("torchvision.models")
+    tv.transforms = stub("torchvision.transforms")
+    stub("labml", monit=types.SimpleNamespace(iterate=lambda n, it: it, enum=lambda n, it: enumerate(it)))
+    stub("omegaconf", OmegaConf=object)
+    sys.path.insert(0, REF)
+    import utils
+    return utils, PrettyMIDI
+
+
+def main():
+    utils, PM = import_utils()
+    out = {}
+    for name, seed, n, steps in (("a", 11, 3, 128), ("b", 12, 2, 64), ("c", 13, 1, 32)):
+        x = synth.prmat2c_image(seed, n, steps)
+        out[f"{name}_seed"], out[f"{name}_shape"] = seed, np.array(x.shape)
+        out[f"{name}_prmat"] = utils.prmat2c_to_prmat(x)
+        mask = (np.random.Generator(np.random.PCG64(seed + 100)).random((n, 2, steps, 128)) < 0.5).astype(np.float32)
+        for tag, kw in (("plain", {}), ("mask", {"inp_mask": mask}), ("custom", {"is_custom_round": True})):
+            utils.prmat2c_to_midi_file(x, "unused.mid", **kw)
+            midi = PM.last
+            rows = [(i, nt.pitch, nt.start, nt.end, nt.velocity) for i, ins in enumerate(midi.instruments) for nt in ins.notes]
+            out[f"{name}_{tag}_notes"] = np.array(rows, dtype=np.float64).reshape(-1, 5)
+            out[f"{name}_{tag}_ninstr"] = len(midi.instruments)
+    np.savez_compressed(os.path.join(OUT, "notes.npz"), **out)
+    print("notes.npz", os.path.getsize(os.path.join(OUT, "notes.npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
