@@ -149,6 +149,8 @@ size_t pf_packed_gemm_weight_floats(int n, int k, int taps);
 int pf_pack_gemm_weight(const float* w, int n, int k, int taps, float* dst);
 /* same bytes, bf16x3 packing [kh*kw][K/8][hi|lo][Npad][8] (bf16); needs k % 8 == 0 */
 int pf_pack_gemm_weight_bf16x3(const float* w, int n, int k, int taps, void* dst);
+/* [n][k][3][3] conv weight of an UpSample layer -> folded packing [4 parities x 4 taps][k/8][plane][Npad][8] (host; k % 8 == 0) */
+int pf_pack_upfold_weight_bf16x3(const float* w, int n, int k, void* dst);
 
 /* GroupNorm statistics on NHWC (optionally the channel-concat of two tensors) -> per-(b,c)
  * scale/shift so that y = x*scale + shift equals GroupNorm(x) (unet.py:321-336; eps 1e-5 / 1e-6). */
@@ -185,6 +187,9 @@ typedef struct pf_conv_args {
    * skip_connection conv folded into its second 3x3 conv, unet.py:262-277): out += skip_w . concat(skip_x0, skip_x1) + skip_bias.
    * bf16x3, ks = 3, stride 1, no upsampling; skip_w is the bf16x3 packing of the [n][skip_c0+skip_c1] weight, channel
    * counts multiples of 32. */
+  /* ups = 1 only: `w` is the PARITY-FOLDED bf16x3 packing (pf_pack_upfold_weight_bf16x3) - nearest x2 upsampling followed by a
+   * 3x3 conv equals, per output parity (y&1, x&1), a 2x2 conv on the source grid with row/column-summed weights: 4/9 of the MACs */
+  int32_t ups_fold;
   const float* skip_x0; int32_t skip_c0;
   const float* skip_x1; int32_t skip_c1;
   const void* skip_w;

@@ -50,6 +50,7 @@ class ConvArgs(C.Structure):
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t),
         ("a_planes", C.c_int32), ("out_planes", C.c_void_p),
         ("qkv_planes", C.c_void_p),
+        ("ups_fold", C.c_int32),
         ("skip_x0", C.c_void_p), ("skip_c0", C.c_int32), ("skip_x1", C.c_void_p), ("skip_c1", C.c_int32),
         ("skip_w", C.c_void_p), ("skip_bias", C.c_void_p),
     ]
@@ -90,6 +91,7 @@ SIGNATURES = {
     "pf_packed_gemm_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "pf_pack_gemm_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pf_pack_gemm_weight_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pf_pack_upfold_weight_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pf_unet_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_unet_get_precision": (C.c_int, [C.c_void_p]),
     "pf_gn_scale_shift": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,

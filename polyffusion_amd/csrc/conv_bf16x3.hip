@@ -18,6 +18,8 @@
 //     consecutive-k B operands are one 16-byte LDS read per plane;
 //   * BK = 32; the 3x3 halo image is single-buffered (it changes every 9 taps; its global loads are
 //     issued three taps ahead), weight tiles are double-buffered; 1x1 mode double-buffers both.
+#include <vector>
+
 #include "conv_common.h"
 
 namespace pf {
@@ -48,10 +50,10 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   constexpr int NW = TOTW / NT;
   constexpr int TAPS = KS * KS;
   constexpr int NABUF = (KS == 1) ? 2 : 1;
-  constexpr int WRING = (KS == 1) ? 2 : 3;   // W tile buffers (3x3: direct-to-LDS ring, prefetch WRING-1 tiles ahead)
+  constexpr int WRING = (KS == 3) ? 3 : 2;   // W tile buffers (3x3: direct-to-LDS ring of 3; the 4-tap folded conv: ring of 2)
   constexpr int WM = BM / NWM, WN = BN / 2;
   constexpr int FM = WM / 32, FN = WN / 32;
-  constexpr int PAD = (KS == 3) ? 1 : 0;
+  constexpr int PAD = (KS == 3) ? 1 : 0;   // KS == 2 (parity-folded upsampling conv): the pad depends on the parity, see iy0
   constexpr int APLANE = NABUF * NPIX * PITCH;  // bf16 elements per A plane
   static_assert(TOTW % NT == 0 && FM >= 1 && FN >= 1, "bad tile");
 
@@ -76,6 +78,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
+  int q = 0;                           // KS == 2: output parity (py, px) = (q >> 1, q & 1); the four parities of a source
+  if constexpr (KS == 2) { q = lid & 3; lid >>= 2; p.fold_py = q >> 1; p.fold_px = q & 1; }   // tile run together (shared halo in L2)
   const int sidx = lid % p.ksplit;   // K-slice (fastest varying: the slices of a tile run together and share its halo in L2)
   lid /= p.ksplit;
   const int nti = lid % p.nt;
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   const int b = mt / p.tiles_y;
   const int n0 = nti * BN;
   const int oy0 = ty * TH, ox0 = tx * TW;
-  const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
+  // KS == 2: output row 2y+py reads source rows {y-1, y} (py = 0) or {y, y+1} (py = 1); same for columns
+  const int iy0 = KS == 2 ? oy0 - 1 + (q >> 1) : oy0 * STRIDE - PAD, ix0 = KS == 2 ? ox0 - 1 + (q & 1) : ox0 * STRIDE - PAD;
   const int Hlog = UPS ? 2 * p.Hin : p.Hin, Wlog = UPS ? 2 * p.Win : p.Win;
   const int cin = p.c0 + p.c1;
   const int K8 = cin / 8;
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     for (int i = 0; i < NA; ++i) {
       // unconditional (padding / out-of-tile pieces read pixel 0 and are zeroed by the transform): the number of
       // vector loads in flight is then a compile-time constant, which the counted vmcnt waits of the 3x3 loop rely on
-      if (KS == 3 || poff[i] >= 0) ra[i] = *reinterpret_cast<const f32x4*>(src + co + (unsigned)(max(poff[i], 0) * cs + c4 * 4));
+      if (KS != 1 || poff[i] >= 0) ra[i] = *reinterpret_cast<const f32x4*>(src + co + (unsigned)(max(poff[i], 0) * cs + c4 * 4));
       else ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (PRO == 1 || PRO == 2) {
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   const size_t wrow = (size_t)2 * p.Npad * 8;   // bf16 elements per k8 row pair (hi|lo planes)
   const __bf16* gw0 = static_cast<const __bf16*>(p.w) + ((size_t)((tid / (2 * BN)) * 2 + ((tid / BN) & 1)) * p.Npad + n0 + tid % BN) * 8;
   auto gldsW = [&](int chunk, int tap, int buf) {
-    const size_t toff = ((size_t)tap * K8 + (size_t)(cbeg + chunk) * 4) * wrow;
+    const size_t toff = ((size_t)(q * TAPS + tap) * K8 + (size_t)(cbeg + chunk) * 4) * wrow;   // q != 0 only for the folded conv
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       __bf16* l = sW + buf * (TOTW * 8) + (wave * 64 + j * NT) * 8;   // wave-uniform base; the hardware adds lane*16 B
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     // One barrier per tap.  At a chunk boundary the halo buffer is rewritten right after the barrier of tap 8 (every wave
     // holds its last A fragments by then) and a second barrier publishes it before the next chunk's A fragments are read.
     constexpr int NS = BK / 16;
-    static_assert(NS == 2 && WRING == 3 && TAPS % WRING == 0, "pipeline is written for two K steps per tap and a 3-slot ring");
+    static_assert(NS == 2 && WRING >= 2 && WRING <= TAPS && TAPS % WRING == 0, "pipeline is written for two K steps per tap and a ring that divides the taps");
     constexpr int NAL = NA + (PRO != 0 ? 2 : 0);   // vector loads issued by loadA (all unconditional)
 #pragma unroll
     for (int d = 0; d < WRING; ++d) gldsW(0, d, d);
@@ -341,18 +346,19 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
         Z(); SB(); LD_BH(slot, 1); SB();
         lgkm_wait<FM + FN>(); SB();
         Y();
-        if (has_next) {   // the next halo's normalise/activate/split arithmetic, spread over taps 2..7
+        if (has_next) {   // the next halo's normalise/activate/split arithmetic, spread over the middle taps (2..7 of 9, 1..2 of 4)
+          constexpr int T0 = TAPS >= 9 ? 2 : 1, TSPAN = TAPS - 1 - T0;
 #pragma unroll
           for (int i = 0; i < NA; ++i)
-            if (tap == 2 + (i * 6) / NA) transformPiece(i);
+            if (tap == T0 + (i * TSPAN) / NA) transformPiece(i);
         }
         SB(); LD_AH(aoff, 1); LD_BL(slot, 1); SB();
         lgkm_wait<FM + FN>(); SB();
         X(); SB();
         TR();
-        // the next tile must be complete.  This thread's outstanding vector loads, oldest first, are the next two weight
-        // tiles and (taps 0/1) the NAL halo loads issued during tap 0.  lgkmcnt(0): all reads of this ring slot are done.
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(tap <= 1 ? NW + NAL : NW) : "memory");
+        // the next tile must be complete.  This thread's vector loads issued after it are the WRING-2 newer weight tiles and -
+        // while tile it+1 was issued before this chunk's tap 0 - the NAL halo loads.  lgkmcnt(0): all reads of this slot done.
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((WRING - 2) * NW + (tap < WRING - 1 ? NAL : 0)) : "memory");
         TR();
         __builtin_amdgcn_s_barrier();
         FENCE();
@@ -528,7 +534,7 @@ template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM
 static int launch3_cfg(ConvP& p, hipStream_t stream) {
   constexpr int THIN = (TH - 1) * STRIDE + KS, TWIN = (TW - 1) * STRIDE + KS;
   constexpr int NABUF = (KS == 1) ? 2 : 1;
-  constexpr int WRING = (KS == 1) ? 2 : 3;
+  constexpr int WRING = (KS == 3) ? 3 : 2;
   constexpr size_t lds_main = (size_t)(2 * NABUF * THIN * TWIN * 40 + WRING * 8 * BN * 8) * 2;
   constexpr size_t lds_skip = SKIP ? (size_t)(2 * 2 * TH * TW * 40 + 2 * 8 * BN * 8) * 2 : 0;   // the fused 1x1 phase's double buffers
   constexpr size_t lds = lds_main > lds_skip ? lds_main : lds_skip;
@@ -542,7 +548,7 @@ static int launch3_cfg(ConvP& p, hipStream_t stream) {
     PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
-  const int grid = p.B * p.tiles_y * p.tiles_x * p.nt * p.ksplit;
+  const int grid = p.B * p.tiles_y * p.tiles_x * p.nt * p.ksplit * (KS == 2 ? 4 : 1);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NWM * 128), lds, stream, p);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
@@ -554,6 +560,10 @@ static int dispatch_tile3(ConvP& p, int tile, hipStream_t s) {
     if (tile == 0) return launch3_cfg<1, 1, false, 1, 128, 128, PRO>(p, s);
     if (tile == 1) return launch3_cfg<1, 1, false, 1, 128, 64, PRO>(p, s);
     return launch3_cfg<1, 1, false, 1, 64, 64, PRO>(p, s);
+  } else if constexpr (KS == 2) {
+    if (tile == 0) return launch3_cfg<2, 1, false, 8, 16, 128, PRO>(p, s);
+    if (tile == 1) return launch3_cfg<2, 1, false, 8, 16, 64, PRO>(p, s);
+    return launch3_cfg<2, 1, false, 4, 16, 64, PRO>(p, s);
   } else if constexpr (STRIDE == 2) {
     return launch3_cfg<3, 2, false, 4, 16, 64, PRO>(p, s);
   } else {
@@ -595,6 +605,10 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
       case 2: return dispatch_tile3<1, 1, false, 2>(p, tile, stream);
       default: return dispatch_tile3<1, 1, false, 3>(p, tile, stream);
     }
+  }
+  if (a.ups_fold) {   // tiles walk the source grid; every workgroup stores one parity of its pixels
+    p.Hout = a.hin; p.Wout = a.win; p.fold = 1;
+    return dispatch_tile3<2, 1, false, 0>(p, tile, stream);
   }
   if (a.stride == 2) return dispatch_tile3<3, 2, false, 0>(p, tile, stream);
   int rc = a.ups ? dispatch_tile3<3, 1, true, 0>(p, tile, stream) : dispatch_tile3<3, 1, false, 1>(p, tile, stream);
@@ -639,6 +653,28 @@ void pack_gemm_bf3(void* dst_, const float* src, int n_src, int K, int taps, int
         dst[((base + 1) * Npad + col) * 8 + (k & 7)] = lo;
       }
   }
+}
+
+
+// UpSample = nearest x2 then conv3x3 (ref:unet.py:236-238).  Output pixel (2y+py, 2x+px) only ever sees a 2x2 block of SOURCE
+// pixels: rows {y-1, y} with weights {w[0], w[1]+w[2]} for py = 0, rows {y, y+1} with {w[0]+w[1], w[2]} for py = 1 (columns
+// alike), so the layer is four 2x2 convolutions on the source grid - 16 taps in total instead of 4 x 9.
+void pack_upfold_bf3(void* dst, const float* src, int N, int K, int Npad) {
+  std::vector<float> f((size_t)N * K * 16);
+  static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};   // [parity][tap] -> kernel index range [lo, hi]
+  for (size_t nk = 0; nk < (size_t)N * K; ++nk) {
+    const float* w = src + nk * 9;
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px)
+        for (int dy = 0; dy < 2; ++dy)
+          for (int dx = 0; dx < 2; ++dx) {
+            double acc = 0.0;
+            for (int ky = lo[py][dy]; ky <= hi[py][dy]; ++ky)
+              for (int kx = lo[px][dx]; kx <= hi[px][dx]; ++kx) acc += w[ky * 3 + kx];
+            f[nk * 16 + (py * 2 + px) * 4 + dy * 2 + dx] = (float)acc;
+          }
+  }
+  pack_gemm_bf3(dst, f.data(), N, K, 16, Npad, 0, nullptr);
 }
 
 }  // namespace pf

@@ -41,6 +41,7 @@ struct ConvP {
   float* out; int ld_out;
   float* stats;   // optional [B][tiles][N][2]: per-tile, per-channel (sum, sum of squares) of the stored outputs
   int tiles_x, tiles_y, nt;
+  int fold, fold_py, fold_px;   // parity-folded upsampling conv: tiles walk the SOURCE grid, pixel (y, x) is stored at (2y+py, 2x+px)
   const float* sx0; const float* sx1; int sc0, sc1;   // fused 1x1 projection of a second tensor (ResBlock skip conv)
   const void* sw; const float* bias2;
   void* out_planes;             // result as bf16 hi/lo planes [M][ld_out] | [M][ld_out] instead of fp32 (consumer: gemm_planes_bf3.hip)
@@ -66,6 +67,11 @@ __device__ __forceinline__ float erf_as_f(float x) {
 __device__ __forceinline__ float gelu_erf_f(float g) { return 0.5f * g * (1.0f + erf_as_f(g * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ void store_out(const ConvP& p, size_t idx, float v) { p.out[idx] = v; }
+// flat output pixel index of tile pixel (oy, ox) of sample b
+__device__ __forceinline__ size_t out_pixel(const ConvP& p, int b, int oy, int ox) {
+  if (p.fold) return ((size_t)b * (2 * p.Hout) + 2 * oy + p.fold_py) * (size_t)(2 * p.Wout) + 2 * ox + p.fold_px;
+  return ((size_t)b * p.Hout + oy) * p.Wout + ox;
+}
 
 // out[m][n] = acc + bias[n] + sbias[b][n] + res[m][n]   (or the GeGLU product), NHWC store.
 // When p.stats is set, the workgroup also emits the per-channel sum / sum-of-squares of what it stored, so that the
@@ -84,7 +90,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
         const int pp = wm * WM + fm * 32 + row;
         const int oy = oy0 + pp / TW, ox = ox0 + pp % TW;
         if (oy >= p.Hout || ox >= p.Wout) continue;
-        const size_t m = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+        const size_t m = out_pixel(p, b, oy, ox);
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) {
           const int n = n0 + wn * WN + fn * 32 + (lane & 31);
@@ -243,7 +249,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
 
   if (full) {
     // interior tile: no per-element bounds checks, hoisted per-column terms
-    const size_t mbase = ((size_t)b * p.Hout + oy0) * p.Wout + ox0;
     float cb[FN];
     int ncol[FN];
 #pragma unroll
@@ -262,7 +267,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           const int pp = wm * WM + fm * 32 + row;
-          const size_t m = mbase + (size_t)(pp / TW) * p.Wout + (pp % TW);
+          const size_t m = out_pixel(p, b, oy0 + pp / TW, ox0 + pp % TW);
 #pragma unroll
           for (int fn = 0; fn < FN; ++fn) acc[fm][fn][r] += p.res[m * p.ld_res + ncol[fn]];
         }
@@ -271,7 +276,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int pp = wm * WM + fm * 32 + row;
-        const size_t m = mbase + (size_t)(pp / TW) * p.Wout + (pp % TW);
+        const size_t m = out_pixel(p, b, oy0 + pp / TW, ox0 + pp % TW);
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) {
           const float v = acc[fm][fn][r] + cb[fn];
@@ -290,7 +295,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
         const int pp = wm * WM + fm * 32 + row;
         const int oy = oy0 + pp / TW, ox = ox0 + pp % TW;
         if (oy >= p.Hout || ox >= p.Wout) continue;
-        const size_t m = ((size_t)b * p.Hout + oy) * p.Wout + ox;
+        const size_t m = out_pixel(p, b, oy, ox);
         if (p.geglu) {
           if (FN == 2) {
             const int nv = n0 + wn * WN + (lane & 31);  // packed column of the value half; gate = nv + 32
@@ -334,8 +339,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
     }
     __syncthreads();
     if (tid < BN && n0 + tid < p.N) {
-      const int tile = (oy0 / TH) * p.tiles_x + ox0 / TW;
-      float* dst = p.stats + (((size_t)b * (p.tiles_x * p.tiles_y) + tile) * p.N + n0 + tid) * 2;
+      const int par = p.fold ? 4 : 1;      // a folded upsampling conv emits one statistics tile per (source tile, parity)
+      const int tile = ((oy0 / TH) * p.tiles_x + ox0 / TW) * par + (p.fold ? p.fold_py * 2 + p.fold_px : 0);
+      float* dst = p.stats + (((size_t)b * (p.tiles_x * p.tiles_y * par) + tile) * p.N + n0 + tid) * 2;
       float a0 = 0.f, a1 = 0.f;
 #pragma unroll
       for (int i = 0; i < NWM; ++i) { a0 += red[(i * BN + tid) * 2 + 0]; a1 += red[(i * BN + tid) * 2 + 1]; }

@@ -259,7 +259,7 @@ void conv_tile_shape(const pf_conv_args& a, int tile, int* th, int* tw) {
 // split-K (bf16x3 3x3 only): layers whose tile grid cannot fill the chip (the 16x16 level at batch 16, most levels at
 // small batch) run ksplit K-slices per tile and a reduce kernel that also applies the epilogue
 static int ksplit_wanted(const pf_conv_args& a) {
-  if (a.precision != PF_PREC_BF16X3 || a.ks != 3 || a.stride != 1 || a.geglu) return 1;
+  if (a.precision != PF_PREC_BF16X3 || a.ks != 3 || a.stride != 1 || a.geglu || a.ups_fold) return 1;
   int hout, wout, th, tw;
   conv_out_dims(a, &hout, &wout);
   if ((hout * wout) % 64 != 0) return 1;
@@ -291,6 +291,7 @@ int conv_stats_tiles(const pf_conv_args& a) {
   conv_out_dims(a, &hout, &wout);
   if (conv_ksplit(a) > 1) return hout * wout / 64;   // the reduce kernel emits one statistics tile per 64 rows
   conv_tile_shape(a, conv_pick_tile(a), &th, &tw);
+  if (a.ups_fold) return cdiv(a.hin, th) * cdiv(a.win, tw) * 4;   // tiles walk the source grid, one statistics tile per parity
   return cdiv(hout, th) * cdiv(wout, tw);
 }
 
@@ -317,7 +318,8 @@ double conv_flops(const pf_conv_args& a) {
     if (a.stride == 2) { hout = (hout - 1) / 2 + 1; wout = (wout - 1) / 2 + 1; }
   }
   const double skip = a.skip_w ? (double)(a.skip_c0 + a.skip_c1) : 0.0;   // fused 1x1 projection of a second tensor
-  return 2.0 * a.batch * hout * wout * (double)a.n * (cin * a.ks * a.ks + skip);
+  const double taps = a.ups_fold ? 4.0 : (double)(a.ks * a.ks);   // folded upsampling conv: 2x2 taps per output pixel (work actually done)
+  return 2.0 * a.batch * hout * wout * (double)a.n * (cin * taps + skip);
 }
 
 int launch_conv(const pf_conv_args& a, hipStream_t stream) {
@@ -341,6 +343,8 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
              "conv: qkv planes need ks=1, N = 3*heads*64 and L %% 16 == 0");
 
   PF_REQUIRE(a.precision == PF_PREC_F32 || a.precision == PF_PREC_BF16X3, "conv: bad precision %d", a.precision);
+  PF_REQUIRE(!a.ups_fold || (a.ups && a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.stride == 1 && a.prologue == 0 && !a.res && !a.skip_w),
+             "conv: ups_fold needs ups=1, bf16x3, ks=3, no prologue / residual");
   PF_REQUIRE(!a.skip_w || (a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.stride == 1 && !a.ups && a.skip_x0 && a.skip_c0 > 0 &&
                            a.skip_c0 % 32 == 0 && a.skip_c1 % 32 == 0 && (a.skip_c1 == 0 || a.skip_x1) && !a.geglu),
              "conv: fused skip projection needs bf16x3, ks=3, stride 1, channel counts multiples of 32");

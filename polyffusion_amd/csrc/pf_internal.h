@@ -38,6 +38,7 @@ int conv_stats_tiles(const pf_conv_args& a);
 int conv_ksplit(const pf_conv_args& a);                           // K-split factor this launch uses (1 = none); needs a.splitk_ws
 size_t conv_splitk_ws_bytes(const pf_conv_args& a);              // scratch wanted for the split (0 = would not split)                      // per-sample tiles emitted into stats_out
 void pack_gemm_bf3(void* dst, const float* src, int n_src, int K, int taps, int Npad, int n_off, const int* colmap);
+void pack_upfold_bf3(void* dst, const float* src, int N, int K, int Npad);   // UpSample conv weight -> 4 parities x 4 taps
 
 int launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                      int batch, int n_heads, int d_head, int lq, int lk, hipStream_t stream);

@@ -27,7 +27,7 @@ int set_error(int code, const char* fmt, ...) {
   return code;
 }
 
-enum DestKind { D_RAW = 0, D_GEMM = 1, D_GEGLU_W = 2, D_GEGLU_B = 3, D_CONVOUT = 4 };
+enum DestKind { D_RAW = 0, D_GEMM = 1, D_GEGLU_W = 2, D_GEGLU_B = 3, D_CONVOUT = 4, D_UPFOLD = 5 };
 struct Dest { int kind; size_t off; int taps, K, N, Npad, n_off; };
 struct ParamSpec { std::string key; std::vector<int64_t> shape; std::vector<Dest> dests; bool packed = false; };
 
@@ -36,6 +36,7 @@ struct Layer {
   int cin, cout;
   // offsets (floats) into the packed blob
   size_t gn1_g, gn1_b, w1, b1, gn2_g, gn2_b, w2, b2, wskip, bskip;  // res; conv: w1/b1
+  size_t wfold = 0;                                                   // upsample: parity-folded bf16x3 packing (16 taps)
   int emb_off;                                                        // column offset into the all-ResBlock time-bias matrix
   // spatial transformer
   size_t norm_g, norm_b, pin_w, pin_b, pout_w, pout_b;
@@ -189,6 +190,10 @@ static void build_layer(pf_unet* u, const std::string& p, Layer& L) {
       break;
     case 4:
       L.w1 = u->add_gemm(p + ".conv.weight", L.cout, L.cin, 9);
+      if (L.cin % 8 == 0) {   // bf16x3 mode runs the layer as four 2x2 convs on the source grid
+        L.wfold = u->alloc(pf_unet::gemm_floats(16, L.cin, L.cout));
+        u->params.back().dests.push_back(Dest{D_UPFOLD, L.wfold, 16, L.cin, L.cout, (L.cout + 63) / 64 * 64, 0});
+      }
       L.b1 = u->add_raw(p + ".conv.bias", {L.cout});
       break;
   }
@@ -331,6 +336,7 @@ static int pack_one(const ParamSpec& ps, const float* src, float* blob) {
         pack_gemm(dst, src, d.N, d.K, d.taps, d.Npad, d.n_off);
         if (d.K % 8 == 0) pack_gemm_bf3(dst + (size_t)d.taps * d.K * d.Npad, src, d.N, d.K, d.taps, d.Npad, d.n_off, nullptr);
         break;
+      case D_UPFOLD: pack_upfold_bf3(dst, src, d.N, d.K, d.Npad); break;
       case D_GEGLU_W: {
         const int inner = d.N / 2;
         for (int n = 0; n < d.N; ++n)
@@ -398,7 +404,7 @@ struct Ctx {
   }
   // launch a conv/linear; when `stats` is given, the producer also emits per-tile channel statistics for a later GroupNorm
   // (buffer from the persistent or the temp region, matching the lifetime of the output tensor)
-  void conv(pf_conv_args a, int kind, Tn* stats = nullptr, bool persist = true) {
+  void conv(pf_conv_args a, int kind, Tn* stats = nullptr, bool persist = true, const float* w_bf3 = nullptr) {
     const int cin_ = a.c0 + a.c1;
     const bool bf3 = u->precision == PF_PREC_BF16X3 && cin_ % 32 == 0;
     if (bf3) a.precision = PF_PREC_BF16X3;   // decided before the tile (and thus the statistics layout) is chosen
@@ -414,7 +420,8 @@ struct Ctx {
     }
     prof_begin(kind, conv_flops(a));
     if (!dry && rc == PF_OK) {
-      if (bf3) a.w = a.w + (size_t)a.ks * a.ks * cin_ * ((a.n + 63) / 64 * 64);  // second half of the region = bf16x3 packing
+      if (w_bf3) a.w = w_bf3;                                                       // a packing of its own (folded upsampling conv)
+      else if (bf3) a.w = a.w + (size_t)a.ks * a.ks * cin_ * ((a.n + 63) / 64 * 64);  // second half of the region = bf16x3 packing
       rc = launch_conv(a, s);
     }
     prof_end();
@@ -672,7 +679,13 @@ static int run(pf_unet* u, Ctx& c, const float* x, const int64_t* t, const float
           float* od = c.palloc((size_t)B * (H * 2) * (W_ * 2) * L.cout);
           pf_conv_args a = conv_base(a0.d, a0.c, nullptr, 0, B, H, W_, 3, c.w(L.w1), L.cout, od);
           a.ups = 1; a.bias = c.w(L.b1);
-          c.conv(a, PF_K_CONV3, &o, true);
+          static const bool no_fold = getenv("PF_NO_UPFOLD") != nullptr;   // experiment hook: the 9-tap form
+          if (c.u->precision == PF_PREC_BF16X3 && L.wfold && L.cin % 32 == 0 && !no_fold) {
+            a.ups_fold = 1; a.precision = PF_PREC_BF16X3;
+            c.conv(a, PF_K_CONV3, &o, true, c.dry ? nullptr : c.w(L.wfold));
+          } else {
+            c.conv(a, PF_K_CONV3, &o, true);
+          }
           H *= 2; W_ *= 2;
           break;
         }
@@ -859,6 +872,11 @@ int pf_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batc
                       const float* gamma, const float* beta, float* scale, float* shift, void* scratch, size_t scratch_bytes,
                       void* stream) {
   return launch_gn_scale_shift(x0, c0, x1, c1, batch, hw, groups, eps, gamma, beta, scale, shift, scratch, scratch_bytes, (hipStream_t)stream);
+}
+int pf_pack_upfold_weight_bf16x3(const float* w, int n, int k, void* dst) {
+  PF_REQUIRE(w && dst && n > 0 && k > 0 && k % 8 == 0, "pack_upfold: bad arguments");
+  pack_upfold_bf3(dst, w, n, k, (n + 63) / 64 * 64);
+  return PF_OK;
 }
 int pf_prmat2c_durations(const float* prmat2c, int n, int steps, int custom_round, int32_t* dur, void* stream) {
   return launch_prmat2c_durations(prmat2c, n, steps, custom_round, dur, (hipStream_t)stream);

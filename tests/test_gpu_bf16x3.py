@@ -316,3 +316,32 @@ def test_fused_skip_projection(lib, B, H, W, ch, c0, c1, cout):
     run_conv(lib, splitk_ws=scratch, splitk_ws_bytes=ws_bytes, **{k: v for k, v in kw.items() if v is not None})
     err = (out.cpu() - nhwc(ref)).abs().max().item()
     assert err < TOL_OP, err
+
+
+def pack_upfold(lib, w):
+    n, k = w.shape[0], w.shape[1]
+    dst = torch.zeros(lib.pf_packed_gemm_weight_floats(n, k, 16), dtype=torch.float32)
+    _lib.check(lib.pf_pack_upfold_weight_bf16x3(w.contiguous().data_ptr(), n, k, dst.data_ptr()))
+    return dst.cuda()
+
+
+@pytest.mark.parametrize("B,H,W,c,cout", [(2, 32, 32, 64, 64), (1, 64, 64, 128, 128), (16, 16, 16, 256, 256), (1, 10, 18, 32, 96), (3, 8, 16, 64, 32)])
+def test_upsample_conv_parity_folded(lib, B, H, W, c, cout):
+    """UpSample (nearest x2 + conv3x3, ref:unet.py:218-238) as four 2x2 convs on the source grid with row/column-summed
+    weights: same result as the 9-tap form, 4/9 of the MACs; the per-tile GroupNorm statistics cover every output pixel."""
+    x = rnd((B, c, H, W), 131)
+    w, bias = rnd((cout, c, 3, 3), 132, (1.0 / (c * 9)) ** 0.5), rnd((cout,), 133, 0.1)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, bias, padding=1)
+    out = torch.empty(B, 2 * H, 2 * W, cout, device="cuda")
+    a = _lib.ConvArgs()
+    kw = dict(x0=dev(nhwc(x)), c0=c, batch=B, hin=H, win=W, ks=3, stride=1, ups=1, ups_fold=1, w=pack_upfold(lib, w), n=cout,
+              bias=dev(bias), out=out, ld_out=cout, precision=1)
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    nt = lib.pf_conv_stats_tiles(C.byref(a))
+    stats = torch.zeros(B, nt, cout, 2, device="cuda")
+    run_conv(lib, stats_out=stats, **kw)
+    o = out.cpu()
+    assert (o - nhwc(ref)).abs().max().item() < TOL_OP
+    tot = stats.cpu().sum(1)
+    assert (tot[..., 0] - o.sum((1, 2))).abs().max() < 2e-2 and (tot[..., 1] - (o * o).sum((1, 2))).abs().max() < 2e-2
