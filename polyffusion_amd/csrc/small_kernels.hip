@@ -291,7 +291,9 @@ __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ x
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
         const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)(b0 + min(r, nb - 1)) * ldx + k);
-        acc[r] += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
+        // explicit fused multiply-adds in a fixed order: left to the compiler's contraction heuristics, the unrolled rows can end
+        // up with different roundings, which makes a sample's result depend on its position in the batch
+        acc[r] = fmaf(wv.w, xv.w, fmaf(wv.z, xv.z, fmaf(wv.y, xv.y, fmaf(wv.x, xv.x, acc[r]))));
       }
     }
   } else {

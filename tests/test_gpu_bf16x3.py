@@ -345,3 +345,27 @@ def test_upsample_conv_parity_folded(lib, B, H, W, c, cout):
     assert (o - nhwc(ref)).abs().max().item() < TOL_OP
     tot = stats.cpu().sum(1)
     assert (tot[..., 0] - o.sum((1, 2))).abs().max() < 2e-2 and (tot[..., 1] - (o * o).sum((1, 2))).abs().max() < 2e-2
+
+
+def test_full_size_batch16_properties_bf16x3():
+    """BASELINE.json configs[1] size (B = 16, 128x128, sdf_chd8bar) in the product mode, through size-independent
+    properties: run-to-run bit reproducibility (no atomics anywhere on the path), independence of a sample from the rest of
+    the batch (GroupNorm / attention are per sample), and the n_cond == 1 collapse - the output depends on the condition
+    only through per-sample biases, so equal conditions give equal outputs for equal inputs."""
+    cfg = UNetConfig(d_cond=512)
+    m = UNetModel(in_channels=2, out_channels=2, channels=64, n_res_blocks=2, attention_levels=(2, 3),
+                  channel_multipliers=(1, 2, 4, 4), n_heads=4, tf_layers=1, d_cond=512)
+    m.load_state_dict(synth_unet_state(cfg, 0))
+    m.set_precision("bf16x3")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 2, 128, 128, generator=g).cuda()
+    t = torch.randint(0, 1000, (16,), generator=g).cuda()
+    c = torch.randn(16, 1, 512, generator=g).cuda()
+    x[9], t[9], c[9] = x[2], t[2], c[2]                      # two identical samples at different batch positions
+    a = m(x, t, c).clone()
+    b = m(x, t, c).clone()
+    assert torch.isfinite(a).all() and torch.equal(a, b)    # deterministic
+    assert torch.equal(a[2], a[9])                           # position in the batch does not matter
+    perm = torch.randperm(16, generator=g).cuda()
+    p = m(x[perm].contiguous(), t[perm].contiguous(), c[perm].contiguous())
+    assert torch.equal(p, a[perm])                           # neither does the batch order

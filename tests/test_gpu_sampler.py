@@ -19,12 +19,14 @@ SMALL = UNetConfig(in_channels=2, out_channels=2, channels=32, n_res_blocks=1, a
 LIN = (0.00085, 0.012)
 
 
-@pytest.fixture(scope="module")
-def ldm():
+@pytest.fixture(scope="module", params=["f32", "bf16x3"])
+def ldm(request):
+    """Both arithmetic modes: exact fp32 MFMA and the error-compensated bf16 split (the default of bench.py)."""
     _lib.require_gpu()
     m = UNetModel(in_channels=2, out_channels=2, channels=32, n_res_blocks=1, attention_levels=(1,),
                   channel_multipliers=(1, 2), n_heads=2, tf_layers=1, d_cond=32, img_h=16, img_w=16)
     m.load_state_dict(synth_unet_state(SMALL, 0))
+    m.set_precision(request.param)
     return LatentDiffusion(m, None, 0.18215, 1000, *LIN)
 
 
