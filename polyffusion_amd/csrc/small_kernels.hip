@@ -268,11 +268,15 @@ int launch_time_embed(const int64_t* t, const float* w0, const float* b0, const 
 // ------------------------------------------------------------------ batched mat-vec: y[b][n] = W[n][:] . x[b][:] + bias[n]
 // A wave owns 8 outputs x 8 K-slices (lane = 8*o + j): the 8 lanes of an output stride its weight row in 128-byte
 // pieces, every lane keeps 8 batch-row accumulators, and the cross-lane reduction is 3 shuffles per accumulator.
-// 8 batch rows per block, so a weight row is read once per 8 samples; all loads of a K step are independent.
+// 8 batch rows per block, so a weight row is read once per 8 samples.  The block first stages its 8 input rows in LDS
+// (the only data every output needs), so the global loads of the main loop are the weight pieces alone - independent,
+// unrolled 8 deep, all in flight together - instead of nine dependent-latency loads per K step.
+// Each row's accumulation is an explicit fmaf chain in a fixed order (identical for every row: batch-position invariant).
 __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ x0, int ldx, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y, int ldy, int B, int N,
                                                      int K, int n_per_group, int x_group_stride) {
   constexpr int RB = 8;
+  extern __shared__ __attribute__((aligned(16))) float sx[];   // [RB][K] (vector path only)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int o = lane >> 3, j = lane & 7;
   const int b0 = blockIdx.y * RB;
@@ -280,23 +284,40 @@ __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ x
   const int n = (blockIdx.x * 4 + wave) * 8 + o;
   const int nc = min(n, N - 1);                                       // out-of-range outputs compute a duplicate, never store
   const float* wr = w + (size_t)nc * K;
-  const float* x = x0 + (size_t)(nc / n_per_group) * x_group_stride;  // block-diagonal (grouped) form
   float acc[RB];
 #pragma unroll
   for (int r = 0; r < RB; ++r) acc[r] = 0.f;
-  if ((K % 4 == 0) && (ldx % 4 == 0) && (x_group_stride % 4 == 0)) {
-#pragma unroll 2
-    for (int k = j * 4; k < K; k += 32) {
-      const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+  const bool vec = (K % 32 == 0) && (ldx % 4 == 0) && (x_group_stride % 4 == 0);
+  // the grouped (block-diagonal) form gives every output group its own input slice: stage only when the block shares one
+  const int g_first = (blockIdx.x * 32) / n_per_group, g_last = (min(blockIdx.x * 32 + 31, N - 1)) / n_per_group;
+  if (vec && g_first == g_last) {
+    const float* xg = x0 + (size_t)g_first * x_group_stride;
+    for (int i = threadIdx.x; i < RB * (K / 4); i += 256) {
+      const int r = i / (K / 4), k4 = i % (K / 4);
+      *reinterpret_cast<float4*>(sx + r * K + k4 * 4) = *reinterpret_cast<const float4*>(xg + (size_t)(b0 + min(r, nb - 1)) * ldx + k4 * 4);
+    }
+    __syncthreads();
+    for (int kb = 0; kb < K; kb += 256) {
+      float4 wv[8];
 #pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)(b0 + min(r, nb - 1)) * ldx + k);
-        // explicit fused multiply-adds in a fixed order: left to the compiler's contraction heuristics, the unrolled rows can end
-        // up with different roundings, which makes a sample's result depend on its position in the batch
-        acc[r] = fmaf(wv.w, xv.w, fmaf(wv.z, xv.z, fmaf(wv.y, xv.y, fmaf(wv.x, xv.x, acc[r]))));
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb + (j + 8 * u) * 4;
+        wv[u] = k < K ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb + (j + 8 * u) * 4;
+        if (k < K) {
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            const float4 xv = *reinterpret_cast<const float4*>(sx + r * K + k);
+            acc[r] = fmaf(wv[u].w, xv.w, fmaf(wv[u].z, xv.z, fmaf(wv[u].y, xv.y, fmaf(wv[u].x, xv.x, acc[r]))));
+          }
+        }
       }
     }
   } else {
+    const float* x = x0 + (size_t)(nc / n_per_group) * x_group_stride;
     for (int k = j; k < K; k += 8) {
       const float wv = wr[k];
 #pragma unroll
@@ -315,7 +336,8 @@ int launch_matvec(const float* x, int ldx, const float* w, const float* bias, fl
                   hipStream_t stream, int n_per_group, int x_group_stride) {
   PF_REQUIRE(x && w && y && batch > 0 && n > 0 && k > 0, "matvec: bad arguments");
   if (n_per_group <= 0) { n_per_group = n; x_group_stride = 0; }
-  hipLaunchKernelGGL(matvec_kernel, dim3(cdiv(n, 32), cdiv(batch, 8)), dim3(256), 0, stream, x, ldx, w, bias, y, ldy, batch, n, k,
+  PF_REQUIRE((size_t)8 * k * sizeof(float) <= 64 * 1024, "matvec: K=%d too large for the staged input rows", k);
+  hipLaunchKernelGGL(matvec_kernel, dim3(cdiv(n, 32), cdiv(batch, 8)), dim3(256), (size_t)8 * k * sizeof(float), stream, x, ldx, w, bias, y, ldy, batch, n, k,
                      n_per_group, x_group_stride);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
