@@ -33,9 +33,25 @@ __device__ unsigned long long g_trace[8192];
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM, bool SKIP>
-__global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
-  constexpr int NT = NWM * 128;            // threads: NWM x 2 waves
+// LDS bytes of one wave group: the main loop's halo image + weight ring, or the fused 1x1 phase's double buffers
+template <int KS, int STRIDE, int TH, int TW, int BN, bool SKIP>
+constexpr size_t conv_bf3_group_lds() {
+  constexpr int THIN = (TH - 1) * STRIDE + KS, TWIN = (TW - 1) * STRIDE + KS;
+  constexpr int NABUF = (KS == 1) ? 2 : 1, WRING = (KS == 3) ? 3 : 2;
+  constexpr size_t main_b = (size_t)(2 * NABUF * THIN * TWIN * 40 + WRING * 8 * BN * 8) * 2;
+  constexpr size_t skip_b = SKIP ? (size_t)(2 * 2 * TH * TW * 40 + 2 * 8 * BN * 8) * 2 : 0;
+  return main_b > skip_b ? main_b : skip_b;
+}
+
+// KG = 2: intra-workgroup K split.  When a layer has no more tiles than the chip has CUs (B = 16: the 32x32 and 16x16 levels),
+// one 4-wave workgroup per CU leaves every SIMD with a single wave and nothing to hide latencies behind (used for the 4x16x64
+// tile, i.e. the 16x16 level at B = 16: +2.5 % end to end).  The workgroup then
+// carries TWO 4-wave groups, each running the complete pipeline below on its own half of the K range and its own LDS
+// region (identical instruction streams, so the workgroup barriers line up); group 1 hands its accumulators to group 0
+// through LDS at the end and only group 0 runs the epilogue.  No global reduce pass, no extra HBM traffic.
+template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM, bool SKIP, int KG = 1>
+__global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
+  constexpr int NT = NWM * 128;            // threads of a wave group: NWM x 2 waves
   constexpr int BK = 32;
   constexpr int BM = TH * TW;
   constexpr int THIN = (TH - 1) * STRIDE + KS;
@@ -57,14 +73,16 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   constexpr int APLANE = NABUF * NPIX * PITCH;  // bf16 elements per A plane
   static_assert(TOTW % NT == 0 && FM >= 1 && FN >= 1, "bad tile");
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int kg = KG == 1 ? 0 : threadIdx.x / NT;                       // wave group (K half)
+  unsigned char* smem_raw = smem_all + kg * conv_bf3_group_lds<KS, STRIDE, TH, TW, BN, SKIP>();
   __bf16* sAh = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sAl = sAh + APLANE;
   __bf16* sW = sAl + APLANE;               // [WRING bufs][4 k8][2 planes][BN][8]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = KG == 1 ? threadIdx.x : threadIdx.x % NT, lane = tid & 63, wave = tid >> 6;   // group-local
 #ifdef PF_TRACE
-  const bool trace_on = (tid == 0) && (blockIdx.x == 0 || blockIdx.x == 301 || blockIdx.x == gridDim.x - 1);
+  const bool trace_on = (threadIdx.x == 0) && (blockIdx.x == 0 || blockIdx.x == 301 || blockIdx.x == gridDim.x - 1);
   const int tbase = blockIdx.x == 0 ? 0 : (blockIdx.x == 301 ? 2048 : 4096);
   int tslot = 0;
   TR();
@@ -94,8 +112,9 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   const int Hlog = UPS ? 2 * p.Hin : p.Hin, Wlog = UPS ? 2 * p.Win : p.Win;
   const int cin = p.c0 + p.c1;
   const int K8 = cin / 8;
-  const int cbeg = (cin / BK) * sidx / p.ksplit;              // this workgroup's K-slice [cbeg, cbeg + nchunk) in BK-channel chunks
-  const int nchunk = (cin / BK) * (sidx + 1) / p.ksplit - cbeg;
+  const int nsl = p.ksplit * KG, sl = sidx * KG + kg;       // K slices: across workgroups (split-K) x across wave groups
+  const int cbeg = (cin / BK) * sl / nsl;                     // this wave group's K-slice [cbeg, cbeg + nchunk) in BK-channel chunks
+  const int nchunk = (cin / BK) * (sl + 1) / nsl - cbeg;
 
   const int c4 = tid % KQ;
   int poff[NA];
@@ -443,15 +462,16 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       int arow[FM];
 #pragma unroll
       for (int fm = 0; fm < FM; ++fm) arow[fm] = (wm * WM + fm * 32 + (lane & 31)) * PITCH + 8 * (lane >> 5);
-      const int nch1 = (p.sc0 + p.sc1) / BK;
-      load1(0);
+      const int nchx = (p.sc0 + p.sc1) / BK;
+      const int ch0 = nchx * kg / KG, nch1 = nchx * (kg + 1) / KG;      // this wave group's share (equal shares: dispatch)
+      load1(ch0);
       __syncthreads();                       // every wave is out of the 3x3 loop: its LDS images are dead
       store1(0);
       __syncthreads();
-      for (int chunk = 0; chunk < nch1; ++chunk) {
+      for (int chunk = ch0; chunk < nch1; ++chunk) {
         if (chunk + 1 < nch1) load1(chunk + 1);
-        const int ao = (chunk & 1) * BM * PITCH;
-        const __bf16* cW = w1 + (chunk & 1) * (TOTW * 8) + wbase;
+        const int ao = ((chunk - ch0) & 1) * BM * PITCH;
+        const __bf16* cW = w1 + ((chunk - ch0) & 1) * (TOTW * 8) + wbase;
 #pragma unroll
         for (int s2 = 0; s2 < BK / 16; ++s2) {
           bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
@@ -478,7 +498,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
         }
-        if (chunk + 1 < nch1) store1((chunk + 1) & 1);
+        if (chunk + 1 < nch1) store1((chunk + 1 - ch0) & 1);
         __syncthreads();
       }
     }
@@ -486,7 +506,29 @@ __global__ __launch_bounds__(NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
 
   TR();
   if (p.partial) p.partial += (size_t)sidx * ((size_t)p.B * p.Hout * p.Wout) * p.N;
-  conv_epilogue<TH, TW, BN, FM, FN, NWM>(p, acc, b, oy0, ox0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem_raw));
+  if constexpr (KG == 2) {   // group 1 -> LDS -> group 0 (register-order dump: conflict-free, no index math)
+    float* xch = reinterpret_cast<float*>(smem_all);
+    __syncthreads();            // both groups are done with their LDS regions
+    if (kg == 1) {
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xch[((fm * FN + fn) * 16 + r) * NT + tid] = acc[fm][fn][r];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[fm][fn][r] += xch[((fm * FN + fn) * 16 + r) * NT + tid];
+    }
+    __syncthreads();            // the epilogue reuses this LDS for the statistics
+  }
+  conv_epilogue<TH, TW, BN, FM, FN, NWM>(p, acc, b, oy0, ox0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem_all), kg == 0);
   TR();
 }
 
@@ -530,26 +572,24 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
   }
 }
 
-template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM = 2, bool SKIP = false>
+template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM = 2, bool SKIP = false, int KG = 1>
 static int launch3_cfg(ConvP& p, hipStream_t stream) {
-  constexpr int THIN = (TH - 1) * STRIDE + KS, TWIN = (TW - 1) * STRIDE + KS;
-  constexpr int NABUF = (KS == 1) ? 2 : 1;
-  constexpr int WRING = (KS == 3) ? 3 : 2;
-  constexpr size_t lds_main = (size_t)(2 * NABUF * THIN * TWIN * 40 + WRING * 8 * BN * 8) * 2;
-  constexpr size_t lds_skip = SKIP ? (size_t)(2 * 2 * TH * TW * 40 + 2 * 8 * BN * 8) * 2 : 0;   // the fused 1x1 phase's double buffers
-  constexpr size_t lds = lds_main > lds_skip ? lds_main : lds_skip;
+  constexpr int FMFN = (TH * TW / NWM / 32) * (BN / 2 / 32);
+  constexpr size_t lds_groups = KG * conv_bf3_group_lds<KS, STRIDE, TH, TW, BN, SKIP>();
+  constexpr size_t lds_xch = KG == 2 ? (size_t)FMFN * 16 * NWM * 128 * 4 : 0;   // accumulator hand-over between the wave groups
+  constexpr size_t lds = lds_groups > lds_xch ? lds_groups : lds_xch;
   static_assert(lds <= 160 * 1024, "LDS budget");
   p.tiles_x = cdiv(p.Wout, TW);
   p.tiles_y = cdiv(p.Hout, TH);
   p.nt = cdiv(p.Npad, BN);
-  auto kern = conv_bf3_kernel<KS, STRIDE, UPS, TH, TW, BN, PRO, NWM, SKIP>;
+  auto kern = conv_bf3_kernel<KS, STRIDE, UPS, TH, TW, BN, PRO, NWM, SKIP, KG>;
   static bool attr_done = false;
   if (!attr_done) {
     PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   const int grid = p.B * p.tiles_y * p.tiles_x * p.nt * p.ksplit * (KS == 2 ? 4 : 1);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NWM * 128), lds, stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(KG * NWM * 128), lds, stream, p);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }
@@ -568,6 +608,12 @@ static int dispatch_tile3(ConvP& p, int tile, hipStream_t s) {
     return launch3_cfg<3, 2, false, 4, 16, 64, PRO>(p, s);
   } else {
     if constexpr (!UPS && PRO == 1) {
+      // no more tiles than CUs (and an even number of K chunks): two wave groups per workgroup split K (see the kernel)
+      static const bool no_kg = getenv("PF_NO_KGROUPS") != nullptr;   // experiment hook
+      const int blocks = p.B * cdiv(p.Hout, tile == 2 ? 4 : 8) * cdiv(p.Wout, 16) * cdiv(p.Npad, tile == 0 ? 128 : 64);
+      const bool kg2 = !no_kg && tile == 2 && p.ksplit == 1 && blocks <= 256 && ((p.c0 + p.c1) / 32) % 2 == 0 && (!p.sw || ((p.sc0 + p.sc1) / 32) % 2 == 0);
+      // (measured: splitting the 128x128 tile the same way is neutral - its two waves per SIMD already cover each other)
+      if (kg2 && tile == 2) return p.sw ? launch3_cfg<3, 1, false, 4, 16, 64, 1, 2, true, 2>(p, s) : launch3_cfg<3, 1, false, 4, 16, 64, 1, 2, false, 2>(p, s);
       if (p.sw) {   // fused skip projection: only the ResBlock second-conv configurations are instantiated
         if (tile == 0) return launch3_cfg<3, 1, false, 8, 16, 128, 1, 2, true>(p, s);
         if (tile == 1) return launch3_cfg<3, 1, false, 8, 16, 64, 1, 2, true>(p, s);

@@ -79,8 +79,14 @@ __device__ __forceinline__ size_t out_pixel(const ConvP& p, int b, int oy, int o
 // `red` is LDS scratch of at least 2*NWM*BN floats that no wave is still reading (callers barrier before reuse).
 template <int TH, int TW, int BN, int FM, int FN, int NWM = 2>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][FN], int b, int oy0, int ox0, int n0,
-                                              int wm, int wn, int lane, int tid, float* red) {
+                                              int wm, int wn, int lane, int tid, float* red, bool active = true) {
   constexpr int WM = TH * TW / NWM, WN = BN / 2;
+  // `active` == false: a wave group of the workgroup that holds no results (intra-workgroup K split, conv_bf16x3.hip) - it only
+  // keeps the workgroup's barrier count in step with the active group
+  if (!active) {
+    if (p.stats && !p.partial) { __syncthreads(); __syncthreads(); }
+    return;
+  }
   if (p.partial) {   // split-K slice: raw accumulators only
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm)
