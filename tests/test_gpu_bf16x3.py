@@ -369,3 +369,23 @@ def test_full_size_batch16_properties_bf16x3():
     perm = torch.randperm(16, generator=g).cuda()
     p = m(x[perm].contiguous(), t[perm].contiguous(), c[perm].contiguous())
     assert torch.equal(p, a[perm])                           # neither does the batch order
+
+
+@pytest.mark.parametrize("B", [1, 5])
+def test_full_unet_small_and_odd_batches_vs_oracle(B):
+    """Full-size sdf_chd8bar at batch sizes where other code paths run than at B = 2 / 16: split-K across workgroups
+    (few tiles), the intra-workgroup K split, ragged last mat-vec row group - against the CPU oracle (contract 1e-3)."""
+    from oracle import unet_ref
+    cfg = UNetConfig(d_cond=512)
+    m = UNetModel(in_channels=2, out_channels=2, channels=64, n_res_blocks=2, attention_levels=(2, 3),
+                  channel_multipliers=(1, 2, 4, 4), n_heads=4, tf_layers=1, d_cond=512)
+    st = synth_unet_state(cfg, 0)
+    m.load_state_dict(st)
+    m.set_precision("bf16x3")
+    g = torch.Generator().manual_seed(3 + B)
+    x = torch.randn(B, 2, 128, 128, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    c = torch.randn(B, 1, 512, generator=g)
+    ref = unet_ref.unet_forward(unet_ref.to_torch(st), cfg, x, t, c)
+    err = (m(x.cuda(), t.cuda(), c.cuda()).cpu() - ref).abs().max().item()
+    assert err < 5e-4, err
