@@ -22,8 +22,9 @@ def _stale(target: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    hdrs = [os.path.join(CSRC, "pf_internal.h"), os.path.join(HERE, "..", "include", "pfhip.h")]
-    objs = []
+    # every header is a dependency of every object (conv_common.h carries the shared epilogue and the asm helpers)
+    hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + [os.path.join(HERE, "..", "include", "pfhip.h")]
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
@@ -32,7 +33,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
             cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
+    if jobs:   # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            for rc in ex.map(lambda c: subprocess.run(c).returncode, jobs):
+                if rc != 0:
+                    raise subprocess.CalledProcessError(rc, "hipcc")
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
