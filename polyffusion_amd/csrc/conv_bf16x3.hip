@@ -16,8 +16,13 @@
 //     transform, 3.5 VALU ops per element, once per element per block);
 //   * weights are pre-split on the host and packed [tap][K/8][plane][Npad][8] so that a lane's eight
 //     consecutive-k B operands are one 16-byte LDS read per plane;
-//   * BK = 32; the 3x3 halo image is single-buffered (it changes every 9 taps; its global loads are
-//     issued three taps ahead), weight tiles are double-buffered; 1x1 mode double-buffers both.
+//   * BK = 32; the 3x3 halo image is single-buffered (it changes every 9 taps; its global loads and its
+//     normalise/activate/split arithmetic are spread over the taps before), weight tiles stream
+//     global->LDS directly through a 3-slot ring, fragments are software-pipelined with hand-counted
+//     LDS waits (see the loop); 1x1 mode is register-staged and double-buffers both operands;
+//   * optional phases / variants around the same loop: the ResBlock's 1x1 skip projection as an
+//     extra K range (SKIP), parity-folded UpSample convs as 2x2 taps on the source grid (KS == 2),
+//     split-K across workgroups (ksplit) and across two wave groups of one workgroup (KG == 2).
 #include <vector>
 
 #include "conv_common.h"
