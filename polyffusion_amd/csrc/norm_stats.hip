@@ -68,14 +68,21 @@ __global__ __launch_bounds__(64) void gn_finalize_tiles_kernel(const float* __re
   const int C = c0 + c1;
   const int gs = C / groups;
   double a = 0.0, q = 0.0;
-  for (int ci = 0; ci < gs; ++ci) {
-    const int c = g * gs + ci;
-    const float* src; int T, cs, cl;
-    if (c < c0) { src = s0; T = t0; cs = c0; cl = c; } else { src = s1; T = t1; cs = c1; cl = c - c0; }
-    for (int t = lane; t < T; t += 64) {
-      const float2 v = *reinterpret_cast<const float2*>(src + (((size_t)b * T + t) * cs + cl) * 2);
-      a += v.x; q += v.y;
-    }
+  // the group's channels that live in source 0 / source 1 (a group may straddle the concat boundary); lanes stride the
+  // flattened (tile, channel) pairs of each part, so the loads of one lane are few and independent even when a tensor has
+  // only a handful of tiles (16x16 level: 4 tiles x 8 channels = one load per lane instead of a chain of eight)
+  const int cb = g * gs, ce = cb + gs;
+  const int n0 = max(0, min(ce, c0) - cb);            // channels [cb, cb + n0) from source 0
+  for (int i = lane; i < n0 * t0; i += 64) {
+    const int t = i / n0, cl = cb + i % n0;
+    const float2 v = *reinterpret_cast<const float2*>(s0 + (((size_t)b * t0 + t) * c0 + cl) * 2);
+    a += v.x; q += v.y;
+  }
+  const int n1 = gs - n0, cb1 = max(cb, c0) - c0;     // channels [cb1, cb1 + n1) of source 1
+  for (int i = lane; i < n1 * t1; i += 64) {
+    const int t = i / n1, cl = cb1 + i % n1;
+    const float2 v = *reinterpret_cast<const float2*>(s1 + (((size_t)b * t1 + t) * c1 + cl) * 2);
+    a += v.x; q += v.y;
   }
   for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); q += __shfl_xor(q, off); }
   const double cnt = (double)gs * hw;
