@@ -8,7 +8,8 @@ autoregressive 4-bar inpainting schedule (:202-303), ``get_autoreg_data`` (:121-
 ``dummy_cond_input`` (:60-72) and ``get_mask`` (:132-193).
 
 Not rebuilt (out of the hot-path scope): dataset / MIDI readers, chord
-extraction, Polydis comparison.  Conditions therefore come from ``--cond_npz`` (arrays
+extraction, Polydis comparison.  Conditions therefore come from ``--from_song_npz`` (a quantised song in the reference's data-dictionary format,
+segmented by ``polyffusion_amd.datasample``), from ``--cond_npz`` (arrays
 ``chord`` [B,32,36] and/or ``prmat`` [B,128,128], optional ``prmat2c`` for inpainting) or from the
 seeded synthetic generator (``--synthetic``); the result is written as ``.mid`` (polyffusion_amd.midi) and ``.npy`` ([B,2,128,128] piano
 roll, or [2B,2,64,128] half-segments for ``--autoreg``).  ``--synthetic_weights`` replaces the
@@ -25,7 +26,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import midi, synth
+from . import datasample, midi, synth
 from .model_sdf import ChordEncoder, Polyffusion_SDF, TextureEncoder
 from .params import Params, find_params, load_params, preset
 from .sampler import DDIMSampler, DiffusionSampler, SDFSampler
@@ -286,6 +287,9 @@ def make_parser() -> ArgumentParser:
     p.add_argument("--synthetic_weights", action="store_true", help="deterministic synthetic weights instead of a checkpoint")
     p.add_argument("--synthetic", action="store_true", help="seeded synthetic chords / textures as conditions")
     p.add_argument("--cond_npz", help="npz with arrays chord [B,32,36] and/or prmat [B,128,128] (and prmat2c for inpainting)")
+    p.add_argument("--from_song_npz", help="a quantised song in the reference's data-dictionary format (notes, start_table, db_pos, "
+                   "db_pos_filter, chord - what get_data_for_single_midi / the POP909 .npz files hold): its 8-bar segments supply the "
+                   "chord / texture conditions and the image to inpaint (ref:inference_sdf.py:599-610 via data/datasample.py)")
     p.add_argument("--bar_list", help="bars to inpaint for --inpaint_type bars, comma separated")
     return p
 
@@ -325,7 +329,10 @@ def main(argv=None):
         print(f"Generating song {i} of {args.num_generate}")
         length = args.length
         chd = prmat = prmat2c_inp = None
-        if args.uncond_scale == 0.0 and args.cond_npz is None and not args.synthetic:
+        if args.from_song_npz is not None:
+            p2c, _, chd, prmat = datasample.DataSample.from_npz(args.from_song_npz).get_whole_song_data()
+            chd, prmat, prmat2c_inp = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev())
+        elif args.uncond_scale == 0.0 and args.cond_npz is None and not args.synthetic:
             if length <= 0:
                 raise SystemExit("--length is required for unconditional generation")
             _, _, chd, prmat = dummy_cond_input(length, params)
@@ -339,7 +346,7 @@ def main(argv=None):
             chd = torch.from_numpy(synth.chords(n, seed + 100 + i)).to(_dev())
             prmat = torch.from_numpy(synth.prmat(n, seed + 200 + i)).to(_dev())
         else:
-            raise SystemExit("no condition source: use --cond_npz, --synthetic or --uncond_scale 0 --length N")
+            raise SystemExit("no condition source: use --from_song_npz, --cond_npz, --synthetic or --uncond_scale 0 --length N")
 
         if args.ddim:
             sampler = DDIMSampler(model.ldm, args.ddim_steps, args.ddim_discretize, args.ddim_eta, seed=seed + i)
@@ -354,7 +361,7 @@ def main(argv=None):
             cond_mid = cond_mid[:length] if cond_mid is not None else None
         if args.inpaint_type is not None:
             if prmat2c_inp is None:
-                raise SystemExit("--inpaint_type needs prmat2c in --cond_npz")
+                raise SystemExit("--inpaint_type needs prmat2c in --cond_npz (or a --from_song_npz song)")
             n = min(cond.shape[0], prmat2c_inp.shape[0])
             bars = [int(v) for v in args.bar_list.split(",")] if args.bar_list else None
             gen = expmt.inpaint(prmat2c_inp[:n], args.inpaint_type, cond[:n], None if cond_mid is None else cond_mid[:n],

@@ -45,3 +45,28 @@ def prmat2c_image(seed: int, n: int, steps: int = 128) -> np.ndarray:
     idx = rng.choice(flat.size, 600, replace=False)
     flat[idx] = rng.choice(np.array([0.5, 1.5, -0.5, 0.95, 1.05, 1.0, 0.50000006, 0.49999997], dtype=np.float32), 600)
     return x
+
+
+def song_data(seed: int, n_bars: int = 20) -> dict:
+    """A quantised song in the dictionary format of the reference's ``get_data_for_single_midi`` / POP909 ``.npz`` files
+    (notes [N,5], start_table, db_pos, db_pos_filter, chord [beats,14]); 4 bins per beat, 4 beats per bar."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n_bins = n_bars * 16
+    rows = []
+    for o in range(n_bins):
+        for _ in range(int(rng.integers(0, 3))):
+            rows.append((o, int(rng.integers(36, 96)), int(rng.integers(1, 24)), int(rng.integers(40, 110)), 0))
+    notes = np.array(rows, dtype=np.int64).reshape(-1, 5)
+    start_table, r = {}, 0
+    for o in range(n_bins + 1):
+        while r < len(notes) and notes[r, 0] < o:
+            r += 1
+        start_table[o] = r
+    db_pos = np.arange(0, n_bins, 16, dtype=np.int64)
+    filt = np.ones(len(db_pos), dtype=bool)
+    filt[-2:] = False                                  # like the reference: the last downbeats cannot start a segment
+    chord = np.zeros((n_bars * 4, 14), dtype=np.int64)
+    chord[:, 0] = rng.integers(0, 12, n_bars * 4)
+    chord[:, 1:13] = rng.random((n_bars * 4, 12)) < 0.3
+    chord[:, 13] = rng.integers(0, 12, n_bars * 4)
+    return {"notes": notes, "start_table": np.array(start_table, dtype=object), "db_pos": db_pos, "db_pos_filter": filt, "chord": chord}
