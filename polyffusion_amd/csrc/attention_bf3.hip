@@ -107,14 +107,13 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
   // direct-to-LDS loads are spread over the S steps and the hi/lo split of the next key block's probabilities is
   // interleaved with the MFMAs of the current one.  LDS waits are counted by hand (inline-asm reads, conv_common.h).
   // One barrier per tile: it publishes tile t and frees the other stage for tile t+1.
-  auto psplit = [&](const f32x16& sv, int half, bf16x8& ph, bf16x8& pl) {
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  auto psplit = [&](const f32x16& sv, int half, bf16x8& ph, bf16x8& pl) {   // whole-vector conversions (packed cvt path)
+    f32x8 v;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float v = sv[half * 8 + q];
-      const __bf16 hi = (__bf16)v;
-      ph[q] = hi;
-      pl[q] = (__bf16)(v - (float)hi);
-    }
+    for (int q = 0; q < 8; ++q) v[q] = sv[half * 8 + q];
+    ph = __builtin_convertvector(v, bf16x8);
+    pl = __builtin_convertvector(v - __builtin_convertvector(ph, f32x8), bf16x8);
   };
   auto tile_body = [&](auto stc, int t) {
     constexpr int ST = decltype(stc)::value;

@@ -183,12 +183,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
       if (!cok || rl >= TH * TW || ox0 + rl >= L) continue;
       const f32x4 a = *reinterpret_cast<const f32x4*>(red + rl * pitch + col) + ra[it];
       const f32x4 c = *reinterpret_cast<const f32x4*>(red + rl * pitch + col + 4) + rc[it];
-      bf16x8_t hi, lo;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        hi[j] = (__bf16)a[j]; lo[j] = (__bf16)(a[j] - (float)hi[j]);
-        hi[4 + j] = (__bf16)c[j]; lo[4 + j] = (__bf16)(c[j] - (float)hi[4 + j]);
-      }
+      // whole-vector conversions: the packed v_cvt_pk_bf16_f32 path (element-wise casts fall back to integer rounding code)
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      const bf16x4_t ha = __builtin_convertvector(a, bf16x4_t), hc = __builtin_convertvector(c, bf16x4_t);
+      const bf16x4_t la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x4), bf16x4_t);
+      const bf16x4_t lc = __builtin_convertvector(c - __builtin_convertvector(hc, f32x4), bf16x4_t);
+      const bf16x8_t hi = __builtin_shufflevector(ha, hc, 0, 1, 2, 3, 4, 5, 6, 7);
+      const bf16x8_t lo = __builtin_shufflevector(la, lc, 0, 1, 2, 3, 4, 5, 6, 7);
       const size_t o = ((size_t)b * L + ox0 + rl) * pq_ld + pq_n0 + col;
       *reinterpret_cast<bf16x8_t*>(pq + o) = hi;
       *reinterpret_cast<bf16x8_t*>(pq + pq_plane + o) = lo;
@@ -231,13 +232,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
             if (t0 >= L) continue;
             const int qd = (t0 >> 2) & 3;
             const int qp = (qd == 1) ? 2 : (qd == 2 ? 1 : qd);
-            bf16x4_t hi4, lo4;
+            f32x4 v4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float v = acc[fm][fn][4 * rq + j] + bn;
-              hi4[j] = (__bf16)v;
-              lo4[j] = (__bf16)(v - (float)hi4[j]);
-            }
+            for (int j = 0; j < 4; ++j) v4[j] = acc[fm][fn][4 * rq + j] + bn;
+            const bf16x4_t hi4 = __builtin_convertvector(v4, bf16x4_t);
+            const bf16x4_t lo4 = __builtin_convertvector(v4 - __builtin_convertvector(hi4, f32x4), bf16x4_t);
             const size_t off = (size_t)(t0 & ~15) + qp * 4;
             *reinterpret_cast<bf16x4_t*>(pv + off) = hi4;
             *reinterpret_cast<bf16x4_t*>(pv + MC + off) = lo4;

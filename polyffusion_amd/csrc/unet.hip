@@ -526,6 +526,7 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
     c.conv(a, PF_K_GEMM);
   }
   float* t0 = ta; float* t1 = tbuf; float* t2 = tc;
+  bool last_planes = false;
   for (size_t i = 0; i < L.tbs.size(); ++i) {
     const Layer::TB& t = L.tbs[i];
     // x = attn1(LN1(x)) + x
@@ -598,6 +599,9 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
     {
       pf_conv_args a = conv_base(ff, 4 * C, nullptr, 0, B, 1, hw, 1, c.w(t.ff2w), C, t2);
       a.bias = c.w(t.ff2b); a.res = t1; a.ld_res = C; a.a_planes = planes ? 1 : 0;
+      static const bool no_lp = getenv("PF_NO_LAST_PLANES") != nullptr;   // experiment hook
+      last_planes = planes && !no_lp && (i + 1 == L.tbs.size());
+      if (last_planes) a.out_planes = c.dry ? (void*)1 : (void*)t2;   // only proj_out reads it: hand it over as planes
       c.conv(a, PF_K_GEMM);
     }
     std::swap(t0, t2);
@@ -605,7 +609,7 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
   Tn ot;
   {
     pf_conv_args a = conv_base(t0, C, nullptr, 0, B, 1, hw, 1, c.w(L.pout_w), C, out);
-    a.bias = c.w(L.pout_b); a.res = x; a.ld_res = C;
+    a.bias = c.w(L.pout_b); a.res = x; a.ld_res = C; a.a_planes = last_planes ? 1 : 0;
     c.conv(a, PF_K_GEMM, &ot, true);
   }
   return ot;

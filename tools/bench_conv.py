@@ -37,6 +37,8 @@ SHAPES = [
     ("pwide_1024_256_2048", 16, 1, 1024, 256, 0, 2048, 1, 1, 0, 0, 1),
     ("pqkv_1024_256_768", 16, 1, 1024, 256, 0, 768, 1, 1, 0, 0, 3),
     ("pff2_1024_1024_256", 16, 1, 1024, 1024, 0, 256, 1, 1, 0, 0, 4),   # planes in, planes out (+ residual)
+    ("pff2nores_1024_1024_256", 16, 1, 1024, 1024, 0, 256, 1, 1, 0, 0, 5),   # planes out, no residual
+    ("pnores_1024_1024_256", 16, 1, 1024, 1024, 0, 256, 1, 1, 0, 0, 6),      # fp32 out, no residual
 ]
 
 
@@ -72,8 +74,10 @@ def main():
         mode = rest[0] if rest else 0
         if mode == 2:
             a.geglu, a.ld_out, a.out_planes, a.res = 1, n // 2, out.data_ptr(), 0
-        if mode == 4:
+        if mode in (4, 5):
             a.out_planes = out.data_ptr()
+        if mode in (5, 6):
+            a.res = 0
         if mode == 3:
             a.qkv_planes, a.res = out.data_ptr(), 0
         st = torch.cuda.current_stream().cuda_stream
