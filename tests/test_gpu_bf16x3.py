@@ -389,3 +389,13 @@ def test_full_unet_small_and_odd_batches_vs_oracle(B):
     ref = unet_ref.unet_forward(unet_ref.to_torch(st), cfg, x, t, c)
     err = (m(x.cuda(), t.cuda(), c.cuda()).cpu() - ref).abs().max().item()
     assert err < 5e-4, err
+
+
+def test_full_unet_txt_bf16x3_vs_reference_golden(golden):
+    """BASELINE.json configs[3] model (sdf_txt, d_cond 1024) in the product arithmetic mode, against the reference vector."""
+    g = golden("unet_txt_b1.npz")
+    m = _make(UNetConfig(d_cond=1024), 128, 128)
+    x = torch.from_numpy(synth.gaussian((1, 2, 128, 128), int(g["x_seed"]))).cuda()
+    c = torch.from_numpy(synth.gaussian((1, 1, 1024), int(g["cond_seed"]))).cuda()
+    o = m(x, torch.from_numpy(g["t"]).cuda(), c).cpu().numpy()
+    assert np.abs(o - g["out"]).max() < 5e-4
