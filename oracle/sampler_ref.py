@@ -176,3 +176,35 @@ def predict(sampler, cond, d_cond: int, shape: List[int], t_idx: int, noise: tor
         new_half = x0[:, :, half:, :]
         gen.append(new_half)
     return torch.cat(gen, dim=0)
+
+
+def get_mask(orig: torch.Tensor, inpaint_type: str, bar_list=None) -> torch.Tensor:
+    """inference_sdf.py:132-193 - inpainting masks (1 = keep).  Row-by-row like the reference, incl. its quirks:
+    "no onset" is recognised by the edge value (0 for ``below``, 127 for ``above``), the leading fill tests
+    ``!= 0`` for both types, and row 0 falls back to row -1 (wrap-around)."""
+    if inpaint_type == "remaining":
+        return orig.clone()
+    if inpaint_type == "bars":
+        keep = torch.ones_like(orig)
+        for bar in bar_list:
+            keep[:, :, 16 * bar: 16 * (bar + 1), :] = 0
+        return keep
+    if inpaint_type not in ("below", "above"):
+        raise NotImplementedError(inpaint_type)
+    n, steps, pitches = orig.shape[0], orig.shape[2], orig.shape[3]
+    rows = orig[:, 0].reshape(n * steps, pitches)
+    if inpaint_type == "below":
+        edge, none = rows.argmax(dim=1), 0
+    else:
+        edge, none = 127 - rows.flip(1).argmax(dim=1), 127
+    lead = int(edge.nonzero()[0])
+    edge[:lead] = edge[lead]
+    out = torch.zeros_like(rows)
+    for r in range(n * steps):
+        if edge[r] == none:
+            edge[r] = edge[r - 1]
+        if inpaint_type == "below":
+            out[r, int(edge[r]):] = 1
+        else:
+            out[r, : int(edge[r]) + 1] = 1
+    return out.reshape(n, 1, steps, pitches).expand(-1, 2, -1, -1)

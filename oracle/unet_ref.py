@@ -19,14 +19,48 @@ nearest interpolate), so it doubles as the "reference CPU path" timed by
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional
+from typing import Dict, List, NamedTuple, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
 
-from polyffusion_amd.arch import UNetConfig, unet_layout
-
 Tensors = Dict[str, torch.Tensor]
+
+
+class RefConfig(NamedTuple):
+    """The reference ``UNetModel`` constructor arguments (unet.py:35-47).  The oracle is self-contained:
+    any object with these attributes is accepted (the tests pass the product's ``UNetConfig``), nothing
+    is imported from the product package."""
+    in_channels: int = 2
+    out_channels: int = 2
+    channels: int = 64
+    n_res_blocks: int = 2
+    attention_levels: Tuple[int, ...] = (2, 3)
+    channel_multipliers: Tuple[int, ...] = (1, 2, 4, 4)
+    n_heads: int = 4
+    tf_layers: int = 1
+    d_cond: int = 512
+
+
+def block_lists(cfg):
+    """unet.py:70-149 - the constructor's module lists, restated independently of the product's plan
+    builder: returns (input_blocks, middle_block, output_blocks), each block a list of layer kinds
+    ("conv3" | "res" | "st" | "down" | "up")."""
+    n_levels = len(cfg.channel_multipliers)
+    inputs = [["conv3"]]
+    for lvl in range(n_levels):
+        with_attn = lvl in cfg.attention_levels
+        inputs += [["res", "st"] if with_attn else ["res"] for _ in range(cfg.n_res_blocks)]
+        if lvl < n_levels - 1:
+            inputs.append(["down"])
+    outputs = []
+    for lvl in range(n_levels - 1, -1, -1):
+        for j in range(cfg.n_res_blocks + 1):
+            blk = ["res"] + (["st"] if lvl in cfg.attention_levels else [])
+            if lvl > 0 and j == cfg.n_res_blocks:
+                blk.append("up")
+            outputs.append(blk)
+    return inputs, ["res", "st", "res"], outputs
 
 
 def time_step_embedding(t: torch.Tensor, channels: int, max_period: float = 10000.0) -> torch.Tensor:
@@ -91,7 +125,7 @@ def transformer_block(w: Tensors, p: str, x: torch.Tensor, cond: torch.Tensor, n
     return x
 
 
-def spatial_transformer(w: Tensors, p: str, x: torch.Tensor, cond: torch.Tensor, cfg: UNetConfig) -> torch.Tensor:
+def spatial_transformer(w: Tensors, p: str, x: torch.Tensor, cond: torch.Tensor, cfg) -> torch.Tensor:
     """unet_attention.py:26-86 - GN(eps 1e-6), 1x1, tokens [B,HW,C], blocks, 1x1, residual."""
     b, c, h, wd = x.shape
     y = F.group_norm(x, 32, w[f"{p}.norm.weight"], w[f"{p}.norm.bias"], eps=1e-6)
@@ -104,9 +138,9 @@ def spatial_transformer(w: Tensors, p: str, x: torch.Tensor, cond: torch.Tensor,
     return y + x
 
 
-def _run_layers(w: Tensors, prefix: str, layers, x, t_emb, cond, cfg: UNetConfig, trace=None):
+def _run_layers(w: Tensors, prefix: str, layers, x, t_emb, cond, cfg, trace=None):
     """unet.py:199-215 - dispatch by layer type."""
-    for li, (kind, _cin, _cout) in enumerate(layers):
+    for li, kind in enumerate(layers):
         p = f"{prefix}.{li}"
         if kind == "conv3":
             x = F.conv2d(x, w[f"{p}.weight"], w[f"{p}.bias"], padding=1)
@@ -124,17 +158,17 @@ def _run_layers(w: Tensors, prefix: str, layers, x, t_emb, cond, cfg: UNetConfig
     return x
 
 
-def unet_forward(w: Tensors, cfg: UNetConfig, x: torch.Tensor, t: torch.Tensor, cond: torch.Tensor,
+def unet_forward(w: Tensors, cfg, x: torch.Tensor, t: torch.Tensor, cond: torch.Tensor,
                  trace: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
     """unet.py:171-196 - x [B,Cin,H,W] fp32, t [B] int64, cond [B,n_cond,d_cond] fp32."""
-    lay = unet_layout(cfg)
+    input_blocks, middle_block, output_blocks = block_lists(cfg)
     t_emb = time_embed(w, t, cfg.channels)
     skips: List[torch.Tensor] = []
-    for bi, blk in enumerate(lay.input_blocks):
+    for bi, blk in enumerate(input_blocks):
         x = _run_layers(w, f"input_blocks.{bi}", blk, x, t_emb, cond, cfg, trace)
         skips.append(x)
-    x = _run_layers(w, "middle_block", lay.middle_block, x, t_emb, cond, cfg, trace)
-    for bi, blk in enumerate(lay.output_blocks):
+    x = _run_layers(w, "middle_block", middle_block, x, t_emb, cond, cfg, trace)
+    for bi, blk in enumerate(output_blocks):
         x = torch.cat([x, skips.pop()], dim=1)  # x first (unet.py:192)
         x = _run_layers(w, f"output_blocks.{bi}", blk, x, t_emb, cond, cfg, trace)
     x = F.group_norm(x, 32, w["out.0.weight"], w["out.0.bias"], eps=1e-5)

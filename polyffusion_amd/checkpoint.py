@@ -1,0 +1,168 @@
+"""Checkpoint ingestion for the denoising path.
+
+Two on-disk formats exist for trained Polyffusion models:
+
+* legacy ``.pt`` - ``learner.py:70-84`` saves ``{"step", "epoch", "model": state_dict, "optimizer", "scaler"}``;
+  ``models/model_sdf.py:59-84`` (``load_trained``) reads ``["model"]``.
+* Lightning ``.ckpt`` - ``lightning_learner.py:5-13`` wraps the model as ``self.model`` and calls
+  ``save_hyperparameters("params", "param_scheduler")``, so the file holds ``state_dict`` with every key prefixed
+  ``model.`` and ``hyper_parameters["params"]`` as a pickled OmegaConf ``DictConfig`` (``inference_sdf.py:717-732`` loads it
+  through ``LightningLearner.load_from_checkpoint``).
+
+Neither lightning nor omegaconf is needed to read them: a checkpoint is a torch zip archive whose pickle is
+decoded here by a RESTRICTED unpickler - tensors, plain containers and numbers are rebuilt as usual, every
+``omegaconf.*`` / ``lightning*`` / ``pytorch_lightning*`` global is mapped to an inert stand-in that only records
+its state, and anything else is refused (no arbitrary code runs while loading a downloaded checkpoint).
+"""
+from __future__ import annotations
+
+import collections
+import pickle
+import types
+from typing import Any, Dict, Mapping, Optional, Tuple
+
+import torch
+
+State = Dict[str, torch.Tensor]
+
+# module-name prefixes whose classes are replaced by stand-ins
+_STANDIN_PREFIXES = ("omegaconf", "lightning", "pytorch_lightning", "lightning_fabric")
+# exact globals allowed besides torch's own tensor-rebuild helpers
+_ALLOWED = {
+    ("collections", "OrderedDict"): collections.OrderedDict,
+    ("collections", "defaultdict"): collections.defaultdict,
+    ("builtins", "dict"): dict, ("builtins", "list"): list, ("builtins", "tuple"): tuple, ("builtins", "set"): set,
+    ("builtins", "frozenset"): frozenset, ("builtins", "int"): int, ("builtins", "float"): float, ("builtins", "bool"): bool,
+    ("builtins", "str"): str, ("builtins", "bytes"): bytes, ("builtins", "complex"): complex, ("builtins", "slice"): slice,
+    ("builtins", "object"): object,
+    # Python-2 names that protocol-2 pickles use for the same builtins (pickle's own fix_imports table)
+    ("builtins", "long"): int, ("builtins", "unicode"): str, ("builtins", "NoneType"): type(None),
+}
+_TORCH_OK_MODULES = ("torch._utils", "torch.storage", "torch._tensor", "torch.serialization", "torch.nn.parameter")
+_TORCH_OK_NAMES = {"FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage",
+                   "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "Size", "device", "dtype", "Tensor",
+                   "float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8", "bool"}
+
+
+class StandIn:
+    """Inert replacement for a class the image does not have (OmegaConf nodes, Lightning bookkeeping).
+    It accepts any constructor call and keeps whatever state the pickle hands it."""
+    _pf_origin = "?"
+
+    def __init__(self, *args, **kwargs):
+        self._pf_args, self._pf_kwargs = args, kwargs
+
+    def __setstate__(self, state):
+        self._pf_state = state
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+
+    def __reduce_ex__(self, protocol):  # never re-pickled as the original class
+        raise pickle.PicklingError("checkpoint stand-ins are read-only")
+
+
+def _standin_for(module: str, name: str):
+    return type(name, (StandIn,), {"_pf_origin": f"{module}.{name}"})
+
+
+class RestrictedUnpickler(pickle.Unpickler):
+    def find_class(self, module: str, name: str):
+        if module == "__builtin__":   # protocol-2 pickles (torch.save's default) use the Python-2 module name
+            module = "builtins"
+        if module.split(".")[0] in _STANDIN_PREFIXES:
+            return _standin_for(module, name)
+        if (module, name) in _ALLOWED:
+            return _ALLOWED[(module, name)]
+        if module in _TORCH_OK_MODULES or (module == "torch" and name in _TORCH_OK_NAMES):
+            return super().find_class(module, name)
+        if module == "typing" and name == "Any":   # OmegaConf's ContainerMetadata.ref_type
+            return Any
+        if module == "numpy" or module.startswith("numpy."):
+            if name in ("ndarray", "dtype", "_reconstruct", "scalar"):
+                return super().find_class(module, name)
+        if module == "enum" or module == "pathlib":
+            return _standin_for(module, name)
+        raise pickle.UnpicklingError(f"checkpoint refers to {module}.{name}, which this loader does not allow")
+
+
+# what torch.load(pickle_module=...) needs: an object with Unpickler / load / __name__
+_pickle_module = types.SimpleNamespace(Unpickler=RestrictedUnpickler, load=lambda f, **kw: RestrictedUnpickler(f, **kw).load(),
+                                       __name__="polyffusion_amd.checkpoint")
+
+
+def _torch_load(path: str):
+    return torch.load(path, map_location="cpu", pickle_module=_pickle_module, weights_only=False)
+
+
+def plain(obj):
+    """OmegaConf stand-ins -> plain dict / list / scalars (``DictConfig._content`` holds ``AnyNode``s with ``_val``)."""
+    if isinstance(obj, StandIn):
+        d = obj.__dict__
+        if "_content" in d:
+            return plain(d["_content"])
+        if "_val" in d:
+            return plain(d["_val"])
+        return {k: plain(v) for k, v in d.items() if not k.startswith("_")}
+    if isinstance(obj, Mapping):
+        return {plain(k): plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [plain(v) for v in obj]
+    return obj
+
+
+def load_legacy_pt(path: str) -> State:
+    """``{"model": state_dict, ...}`` or a bare state_dict (``utils.py:55-57`` accepts both)."""
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    state = ck["model"] if isinstance(ck, Mapping) and "model" in ck else ck
+    if not isinstance(state, Mapping) or not all(isinstance(k, str) for k in state):
+        raise RuntimeError(f"{path}: not a Polyffusion checkpoint (no state_dict found)")
+    return dict(state)
+
+
+def load_lightning_ckpt(path: str) -> Tuple[State, Optional[dict]]:
+    """Returns (state_dict with the ``model.`` prefix removed, the saved ``params`` as a plain dict or None)."""
+    ck = _torch_load(path)
+    if not isinstance(ck, Mapping) or "state_dict" not in ck:
+        raise RuntimeError(f"{path}: not a Lightning checkpoint (no 'state_dict')")
+    state = {}
+    for k, v in ck["state_dict"].items():
+        if not k.startswith("model."):
+            raise RuntimeError(f"{path}: unexpected key {k!r} (LightningLearner keeps the network under 'model.')")
+        state[k[len("model."):]] = v
+    params = None
+    hp = ck.get("hyper_parameters")
+    if isinstance(hp, Mapping) and hp.get("params") is not None:
+        params = plain(hp["params"])
+        if not isinstance(params, dict):
+            params = None
+    return state, params
+
+
+def load_checkpoint(path: str) -> Tuple[State, Optional[dict]]:
+    """Dispatch on the extension exactly like ``inference_sdf.py:704-734``."""
+    if path.endswith(".pt"):
+        return load_legacy_pt(path), None
+    if path.endswith(".ckpt"):
+        return load_lightning_ckpt(path)
+    raise RuntimeError(f"{path}: unknown checkpoint type (expected .pt or .ckpt)")
+
+
+def split_state(state: Mapping[str, torch.Tensor]):
+    """Full-model state_dict -> (unet, chord_enc, txt_enc) sub-dicts with their prefixes removed.
+    The recomputable schedule buffers and the decode-only modules are dropped; anything else is an error
+    with torch's wording (``unexpected key``)."""
+    unet, ce, te = {}, {}, {}
+    for k, v in state.items():
+        if k.startswith("ldm.eps_model."):
+            unet[k[len("ldm.eps_model."):]] = v
+        elif k.startswith("chord_enc."):
+            ce[k[len("chord_enc."):]] = v
+        elif k.startswith("txt_enc."):
+            te[k[len("txt_enc."):]] = v
+        elif k in ("ldm.alpha", "ldm.beta", "ldm.alpha_bar", "ldm.sigma2"):
+            continue  # recomputed from the params (latent_diffusion.py:90-103)
+        elif k.split(".")[0] in ("chord_dec", "pnotree_enc", "pnotree_dec"):
+            continue  # decode/debug-only modules
+        else:
+            raise RuntimeError(f"unexpected key in checkpoint: {k}")
+    return unet, ce, te

@@ -56,3 +56,46 @@ def max_over_ranks(value: float) -> float:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return value
+
+
+def broadcast_int(value: int, src: int = 0) -> int:
+    """Rank ``src``'s integer on every rank (e.g. a randomly drawn seed)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([int(value)], dtype=torch.int64, device="cuda" if torch.cuda.is_available() else "cpu")
+        dist.broadcast(t, src=src)
+        return int(t.item())
+    return int(value)
+
+
+def gather_rows(local: torch.Tensor, total: int, rank: int, world: int) -> torch.Tensor:
+    """Concatenate the ranks' row blocks (rank r holds rows ``shard_range(total, r, world)``) on every rank.
+
+    The end-of-run exchange of SURVEY.md 8e: ``all_gather`` needs equal shapes, so every rank pads its block to the
+    largest shard (``ceil(total / world)`` rows) and the padding is dropped after the collective."""
+    lo, hi = shard_range(total, rank, world)
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"gather_rows: rank {rank} holds {local.shape[0]} rows, expected {hi - lo}")
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return local
+    cap = -(-total // world)
+    padded = local.new_zeros((cap, *local.shape[1:]))
+    padded[: hi - lo] = local
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded.contiguous())
+    out = []
+    for r, part in enumerate(parts):
+        a, b = shard_range(total, r, world)
+        out.append(part[: b - a])
+    return torch.cat(out, dim=0)
+
+
+def ranks_seen():
+    """(world size the process group reports, the device index every rank runs on) - bench.py prints it so a run that
+    silently fell back to fewer ranks is visible in the JSON line."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        me = torch.tensor([torch.cuda.current_device() if torch.cuda.is_available() else -1], dtype=torch.int64,
+                          device="cuda" if torch.cuda.is_available() else "cpu")
+        parts = [torch.empty_like(me) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, me)
+        return dist.get_world_size(), [int(p.item()) for p in parts]
+    return 1, [torch.cuda.current_device() if torch.cuda.is_available() else -1]

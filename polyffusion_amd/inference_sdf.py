@@ -145,26 +145,42 @@ class Experiments:
         return gen
 
     @torch.no_grad()
-    def predict_songs(self, cond: torch.Tensor, cond_mid: torch.Tensor, uncond_scale=1.0):
-        """Autoregressive generation batched ACROSS songs (config 5): cond/cond_mid are [S, B, 1, d_cond];
-        the 2B-1 runs stay sequential within a song but each run denoises all S songs at once.
-        Returns [S, 2B, C, H/2, W]."""
+    def predict_songs(self, cond: torch.Tensor, cond_mid: torch.Tensor, uncond_scale=1.0, orig=None, mask=None,
+                      cond_concat=None, noise: Optional[torch.Tensor] = None):
+        """``predict(autoreg=True)`` (``inference_sdf.py:227-283``) batched ACROSS songs - BASELINE config 5.
+
+        ``cond`` / ``cond_mid`` are ``[S, B, n_cond, d_cond]`` (S songs of B 8-bar segments); ``orig`` / ``mask`` / ``noise``,
+        when given, ``[S, B, C, H, W]``.  The 2B-1 runs stay sequential within a song (run r needs the half that run r-1
+        produced) but run r of all S songs is one batch of S images, so the denoiser sees batch S instead of batch 1.
+        Song s gets exactly what ``predict(cond[s], cond_mid[s], autoreg=True, ...)`` computes when both are fed the same
+        noise.  With the on-device generator the draws are keyed by (seed, draw counter, global song index): ranks that
+        shard the songs (``sample_offset`` = first song of the rank) reproduce the unsharded run.
+        Returns ``[S, 2B, C, H/2, W]``."""
         p, dev = self.params, cond.device
         S, B = cond.shape[0], cond.shape[1]
-        shape = [S, p.out_channels, p.img_h, p.img_w]
+        shape = [S, B, p.out_channels, p.img_h, p.img_w]
         half = p.img_h // 2
+        if orig is None or mask is None:
+            orig, mask = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
+        else:
+            orig, mask = orig.clone().float(), mask.clone().float()   # edited in place below
+        if noise is None:
+            noise = self.sampler.randn(shape, dev)
+        # half-shifted streams per song: get_autoreg_data rolls along dim 0, so the segment axis goes there
+        mid = lambda v: get_autoreg_data(v.transpose(0, 1), split_dim=3).transpose(0, 1)
+        orig_mid, mask_mid, noise_mid = mid(orig), mid(mask), mid(noise)
         uc = -torch.ones([S, 1, p.d_cond], device=dev)
+        kw = dict(uncond_scale=uncond_scale, uncond_cond=uc, cond_concat=cond_concat, repaint_n=self.repaint_n)
         gen, new_half = [], None
         for idx in range(B * 2 - 1):
-            c_s = (cond_mid if idx % 2 == 1 else cond)[:, idx // 2].contiguous()
-            o_s, m_s = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
-            n_s = self.sampler.randn(shape, dev)
+            src = (cond_mid, orig_mid, mask_mid, noise_mid) if idx % 2 == 1 else (cond, orig, mask, noise)
+            c_s, o_s, m_s, n_s = (v[:, idx // 2] for v in src)
             if idx != 0:
                 o_s[:, :, 0:half, :] = new_half
                 m_s[:, :, 0:half, :] = 1
+            c_s, o_s, m_s, n_s = (v.contiguous() for v in (c_s, o_s, m_s, n_s))
             xt = self.sampler.q_sample(o_s, self.t_idx, n_s)
-            x0 = self.sampler.paint(xt, c_s, self.t_idx, orig=o_s, mask=m_s, orig_noise=n_s, uncond_scale=uncond_scale,
-                                    uncond_cond=uc, repaint_n=self.repaint_n)
+            x0 = self.sampler.paint(xt, c_s, self.t_idx, orig=o_s, mask=m_s, orig_noise=n_s, **kw)
             if idx == 0:
                 gen.append(x0[:, :, 0:half, :])
             new_half = x0[:, :, half:, :]
@@ -294,81 +310,178 @@ def make_parser() -> ArgumentParser:
     return p
 
 
+def load_model(params, args, rank: int = 0, world: int = 1) -> Polyffusion_SDF:
+    """Assemble the model (``inference_sdf.py:536-557,702-734``).  Rank 0 reads the checkpoint (or generates the synthetic
+    weights) and repacks it into the kernel-side blobs; with world > 1 the other ranks receive the packed blobs by ONE
+    broadcast each (RCCL over xGMI) and never touch the file system - SURVEY.md 8e."""
+    from . import _lib, dist as pfdist
+    from .checkpoint import load_checkpoint, split_state
+    unet = build_unet(params)
+    chord_enc, txt_enc = build_encoders(params)
+    parts = [("unet", unet, unet.weight_bytes())]
+    if chord_enc is not None:
+        parts.append(("chord_enc", chord_enc, int(_lib.load().pf_encoder_weight_bytes(chord_enc._h))))
+    if txt_enc is not None:
+        parts.append(("txt_enc", txt_enc, int(_lib.load().pf_encoder_weight_bytes(txt_enc._h))))
+    states = {}
+    if rank == 0:
+        if args.synthetic_weights:
+            from .arch import UNetConfig
+            from .weights import synth_chord_encoder_state, synth_texture_encoder_state, synth_unet_state
+            states["unet"] = synth_unet_state(UNetConfig.from_params(params), 0)
+            if chord_enc is not None:
+                states["chord_enc"] = synth_chord_encoder_state(0, params.chd_input_dim, params.chd_hidden_dim, params.chd_z_dim)
+            if txt_enc is not None:
+                states["txt_enc"] = synth_texture_encoder_state(0, params.txt_emb_size, params.txt_hidden_dim, params.txt_z_dim,
+                                                                params.txt_num_channel)
+        else:
+            path = args.chkpt_path
+            if path and os.path.exists(f"{path}/chkpts/{args.chkpt_name}"):
+                path = f"{path}/chkpts/{args.chkpt_name}"
+            if not path or not (path.endswith(".pt") or path.endswith(".ckpt")):
+                raise SystemExit("--chkpt_path must name a legacy .pt or a Lightning .ckpt checkpoint (or a run directory holding chkpts/)")
+            states["unet"], states["chord_enc"], states["txt_enc"] = split_state(load_checkpoint(path)[0])
+    dev = _dev()
+    for name, mod, nbytes in parts:
+        if rank == 0:
+            if not states.get(name):
+                raise SystemExit(f"checkpoint has no {name} weights")
+            blob = mod.pack_state_dict(states[name]).to(dev)
+        else:
+            blob = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        pfdist.broadcast_blob(blob, 0)
+        mod.bind_packed(blob)
+    return Polyffusion_SDF(build_ldm(params, unet), params.cond_type, params.cond_mode, chord_enc=chord_enc, txt_enc=txt_enc)
+
+
+def make_sampler(model, args, seed: int, sample_offset: int = 0):
+    """(sampler, start index) as ``inference_sdf.py:735-747,215-219`` choose them."""
+    if args.ddim:
+        sampler = DDIMSampler(model.ldm, args.ddim_steps, args.ddim_discretize, args.ddim_eta, seed=seed, sample_offset=sample_offset)
+        t_idx = args.ddim_steps - 1    # inference_sdf.py:218 (NOT len(time_steps)-1: 'uniform' can yield one more entry)
+        if t_idx >= len(sampler.time_steps):
+            raise SystemExit(f"--ddim_steps {args.ddim_steps}: the discretisation has only {len(sampler.time_steps)} steps")
+        return sampler, t_idx
+    return SDFSampler(model.ldm, seed=seed, sample_offset=sample_offset), None
+
+
+def generate_songs(model, params, args, cond, cond_mid, orig, mask, seed: int, rank: int = 0, world: int = 1):
+    """This rank's share of ``args.num_generate`` independent generations of the same conditions.
+
+    The reference loops over the songs (``inference_sdf.py:774``); here they are ONE batch and the unit of multi-GPU
+    sharding: rank r takes the songs ``shard_range(num_generate, r, world)``, keyed into the noise generator by their
+    GLOBAL index (``sample_offset``), so the result does not depend on the number of GPUs, and the step loop has no
+    collective.  Returns (``[n_local, B, C, H, W]`` - or ``[n_local, 2B, C, H/2, W]`` with ``--autoreg`` -, the Experiments)."""
+    from . import dist as pfdist
+    S, B = args.num_generate, cond.shape[0]
+    lo, hi = pfdist.shard_range(S, rank, world)
+    n_local = hi - lo
+    per_song = 1 if args.autoreg else B   # images the sampler sees per song in one paint() call
+    sampler, t_idx = make_sampler(model, args, seed, lo * per_song)
+    expmt = Experiments(params.model_name, params, sampler, t_idx=t_idx, repaint_n=args.repaint_n)
+    rep = lambda v: None if v is None else v.unsqueeze(0).expand(n_local, *v.shape).contiguous()
+    C, H, W = params.out_channels, params.img_h, params.img_w
+    if n_local == 0:
+        gen = torch.empty(0, 2 * B if args.autoreg else B, C, H // 2 if args.autoreg else H, W, device=cond.device)
+    elif args.autoreg:
+        gen = expmt.predict_songs(rep(cond), rep(cond_mid), args.uncond_scale, orig=rep(orig), mask=rep(mask))   # [n,2B,C,H/2,W]
+    else:
+        flat = lambda v: None if v is None else rep(v).reshape(n_local * B, *v.shape[1:])
+        gen = expmt.predict(flat(cond), None, args.uncond_scale, False, flat(orig), flat(mask)).reshape(n_local, B, C, H, W)
+    return gen, expmt
+
+
 def main(argv=None):
+    from . import dist as pfdist
     args = make_parser().parse_args(argv)
     for flag in ("from_dataset", "from_midi", "from_midi2", "inpaint_from_midi", "inpaint_from_dataset", "inpaint_pop909_use_track"):
         if getattr(args, flag) is not None:
             raise SystemExit(f"--{flag}: dataset / MIDI front ends are outside the rebuilt hot path; use --cond_npz or --synthetic")
     if not torch.cuda.is_available():
         raise SystemExit("inference_sdf needs an AMD GPU (no CPU fallback on this path)")
-    seed = args.seed if args.seed is not None else 0
-    torch.manual_seed(seed); np.random.seed(seed); random.seed(seed)
+    rank, world, _ = pfdist.init_from_env()
+    say = print if rank == 0 else (lambda *a, **k: None)
+    if args.seed is not None:
+        seed = args.seed
+    else:
+        # the reference seeds only on request (inference_sdf.py:510-514) and is otherwise random; the counter-based
+        # generator needs SOME key, so draw one, share it across ranks and print it for reproducibility
+        seed = pfdist.broadcast_int(int.from_bytes(os.urandom(4), "little"))
+        say(f"seed: {seed} (pass --seed {seed} to reproduce)")
+    torch.manual_seed(seed); np.random.seed(seed % (2 ** 32)); random.seed(seed)
 
     if args.params_preset is not None:
         params = preset(args.params_preset)
     else:
         if args.chkpt_path is None and args.custom_params_path is None:
             raise SystemExit("give --chkpt_path, --custom_params_path or --params_preset")
-        params = load_params(find_params(args.chkpt_path or ".", args.custom_params_path))
-    print(f"model_label: {params.model_name}")
+        try:
+            params = load_params(find_params(args.chkpt_path or ".", args.custom_params_path))
+        except FileNotFoundError:
+            # extension: a Lightning checkpoint carries its own params (lightning_learner.py:13 save_hyperparameters)
+            if not (args.chkpt_path or "").endswith(".ckpt"):
+                raise
+            from .checkpoint import load_lightning_ckpt
+            saved = load_lightning_ckpt(args.chkpt_path)[1]
+            if saved is None:
+                raise
+            params = Params(saved)
+            params.setdefault("cond_mode", "cond")
+            params.setdefault("use_enc", True)
+    say(f"model_label: {params.model_name}")
+    model = load_model(params, args, rank, world)
 
-    if args.synthetic_weights:
-        model = synthetic_model(params, seed=0)
+    length = args.length
+    chd = prmat = prmat2c_inp = None
+    if args.from_song_npz is not None:
+        p2c, _, chd, prmat = datasample.DataSample.from_npz(args.from_song_npz).get_whole_song_data()
+        chd, prmat, prmat2c_inp = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev())
+    elif args.uncond_scale == 0.0 and args.cond_npz is None and not args.synthetic:
+        if length <= 0:
+            raise SystemExit("--length is required for unconditional generation")
+        _, _, chd, prmat = dummy_cond_input(length, params)
+    elif args.cond_npz is not None:
+        z = np.load(args.cond_npz)
+        chd = torch.from_numpy(z["chord"]).float().to(_dev()) if "chord" in z else None
+        prmat = torch.from_numpy(z["prmat"]).float().to(_dev()) if "prmat" in z else None
+        prmat2c_inp = torch.from_numpy(z["prmat2c"]).float().to(_dev()) if "prmat2c" in z else None
+    elif args.synthetic:
+        n = length if length > 0 else 1
+        chd = torch.from_numpy(synth.chords(n, seed + 100)).to(_dev())
+        prmat = torch.from_numpy(synth.prmat(n, seed + 200)).to(_dev())
     else:
-        path = args.chkpt_path
-        if path and os.path.exists(f"{path}/chkpts/{args.chkpt_name}"):
-            path = f"{path}/chkpts/{args.chkpt_name}"
-        if not path or not path.endswith(".pt"):
-            raise SystemExit("only legacy .pt checkpoints are supported on this path (Lightning .ckpt needs omegaconf)")
-        unet = build_unet(params)
-        chord_enc, txt_enc = build_encoders(params)
-        model = Polyffusion_SDF.load_trained(build_ldm(params, unet), path, params.cond_type, params.cond_mode,
-                                             chord_enc=chord_enc, txt_enc=txt_enc)
+        raise SystemExit("no condition source: use --from_song_npz, --cond_npz, --synthetic or --uncond_scale 0 --length N")
 
-    for i in range(args.num_generate):
-        print(f"Generating song {i} of {args.num_generate}")
-        length = args.length
-        chd = prmat = prmat2c_inp = None
-        if args.from_song_npz is not None:
-            p2c, _, chd, prmat = datasample.DataSample.from_npz(args.from_song_npz).get_whole_song_data()
-            chd, prmat, prmat2c_inp = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev())
-        elif args.uncond_scale == 0.0 and args.cond_npz is None and not args.synthetic:
-            if length <= 0:
-                raise SystemExit("--length is required for unconditional generation")
-            _, _, chd, prmat = dummy_cond_input(length, params)
-        elif args.cond_npz is not None:
-            z = np.load(args.cond_npz)
-            chd = torch.from_numpy(z["chord"]).float().to(_dev()) if "chord" in z else None
-            prmat = torch.from_numpy(z["prmat"]).float().to(_dev()) if "prmat" in z else None
-            prmat2c_inp = torch.from_numpy(z["prmat2c"]).float().to(_dev()) if "prmat2c" in z else None
-        elif args.synthetic:
-            n = length if length > 0 else 1
-            chd = torch.from_numpy(synth.chords(n, seed + 100 + i)).to(_dev())
-            prmat = torch.from_numpy(synth.prmat(n, seed + 200 + i)).to(_dev())
-        else:
-            raise SystemExit("no condition source: use --from_song_npz, --cond_npz, --synthetic or --uncond_scale 0 --length N")
+    cond, cond_mid = encode_conditions(model, params, chd, prmat, args.autoreg)
+    if params.cond_mode == "uncond":
+        cond = -torch.ones_like(cond)
+    if length > 0:
+        cond = cond[:length]
+        cond_mid = cond_mid[:length] if cond_mid is not None else None
+    orig = mask = None
+    if args.inpaint_type is not None:
+        if prmat2c_inp is None:
+            raise SystemExit("--inpaint_type needs prmat2c in --cond_npz (or a --from_song_npz song)")
+        n = min(cond.shape[0], prmat2c_inp.shape[0])
+        cond, orig = cond[:n], prmat2c_inp[:n]
+        cond_mid = None if cond_mid is None else cond_mid[:n]
+        bars = [int(v) for v in args.bar_list.split(",")] if args.bar_list else None
+        mask = get_mask(orig, args.inpaint_type, bars).to(orig.device)
 
-        if args.ddim:
-            sampler = DDIMSampler(model.ldm, args.ddim_steps, args.ddim_discretize, args.ddim_eta, seed=seed + i)
-        else:
-            sampler = SDFSampler(model.ldm, seed=seed + i)
-        expmt = Experiments(params.model_name, params, sampler, repaint_n=args.repaint_n)
-        cond, cond_mid = encode_conditions(model, params, chd, prmat, args.autoreg)
-        if params.cond_mode == "uncond":
-            cond = -torch.ones_like(cond)
-        if length > 0:
-            cond = cond[:length]
-            cond_mid = cond_mid[:length] if cond_mid is not None else None
-        if args.inpaint_type is not None:
-            if prmat2c_inp is None:
-                raise SystemExit("--inpaint_type needs prmat2c in --cond_npz (or a --from_song_npz song)")
-            n = min(cond.shape[0], prmat2c_inp.shape[0])
-            bars = [int(v) for v in args.bar_list.split(",")] if args.bar_list else None
-            gen = expmt.inpaint(prmat2c_inp[:n], args.inpaint_type, cond[:n], None if cond_mid is None else cond_mid[:n],
-                                autoreg=args.autoreg, uncond_scale=args.uncond_scale, bar_list=bars, output_dir=args.output_dir)
-        else:
-            gen = expmt.generate(cond, cond_mid, uncond_scale=args.uncond_scale, autoreg=args.autoreg, output_dir=args.output_dir)
-        print(f"piano_roll: {tuple(gen.shape)}  onsets>0.5: {int((gen[:, 0] > 0.5).sum())}")
+    S, B = args.num_generate, cond.shape[0]
+    say(f"generating {S} song(s) x {B} segment(s) with uncond_scale = {args.uncond_scale} on {world} GPU(s)")
+    gen, expmt = generate_songs(model, params, args, cond, cond_mid, orig, mask, seed, rank, world)
+    gen = pfdist.gather_rows(gen, S, rank, world)   # [S, ...] on every rank (131 KB per image; the only end-of-run exchange)
+    if rank == 0:
+        os.makedirs(args.output_dir, exist_ok=True)
+        for i in range(S):
+            extra = "" if args.inpaint_type is None else f"_inp{args.repaint_n}_{args.inpaint_type}"
+            stamp = os.path.join(args.output_dir, expmt._stamp(args.uncond_scale, args.autoreg, extra) + (f"_{i}" if S > 1 else ""))
+            np.save(stamp + ".npy", gen[i].cpu().numpy())
+            # generated cells on their own track when inpainting (ref:inference_sdf.py:385-389)
+            midi.prmat2c_to_midi_file(gen[i], stamp + ".mid", inp_mask=None if args.autoreg else mask)
+            say(f"song {i}: piano_roll {tuple(gen[i].shape)}  onsets>0.5: {int((gen[i][:, 0] > 0.5).sum())}  -> {stamp}.mid")
+    pfdist.barrier()
     return 0
 
 

@@ -107,7 +107,10 @@ class TextureEncoder(_Encoder):
         return self._run(pr, 8)
 
 
-def _strip(state: Mapping[str, object], part: str):
+def _strip(state, part: str):
+    if isinstance(state, (str, bytes)) or hasattr(state, "__fspath__"):   # a checkpoint path, like the reference's fpath argument
+        from .checkpoint import load_checkpoint
+        state = load_checkpoint(str(state))[0]
     if "model" in state:
         state = state["model"]
     return {".".join(k.split(".")[1:]): v for k, v in state.items() if k.split(".")[0] == part}
@@ -136,28 +139,17 @@ class Polyffusion_SDF:
     @classmethod
     def load_trained(cls, ldm, chkpt_fpath, cond_type, cond_mode="cond", chord_enc=None, chord_dec=None,
                      pnotree_enc=None, pnotree_dec=None, txt_enc=None):
-        """Legacy ``.pt`` checkpoint: ``{"model": state_dict}`` with ``ldm.eps_model.*``, ``chord_enc.*``,
+        """Legacy ``.pt`` (``{"model": state_dict}``, models/model_sdf.py:59-84) or Lightning ``.ckpt``
+        (``model.``-prefixed ``state_dict``, inference_sdf.py:717-732) with ``ldm.eps_model.*``, ``chord_enc.*``,
         ``txt_enc.*`` keys and recomputable schedule vectors ``ldm.{alpha,beta,alpha_bar,sigma2}``."""
+        from .checkpoint import load_checkpoint
         model = cls(ldm, cond_type, cond_mode, chord_enc, chord_dec, pnotree_enc, pnotree_dec, txt_enc)
-        ck = torch.load(chkpt_fpath, map_location="cpu", weights_only=True)
-        model.load_state_dict(ck["model"] if "model" in ck else ck)
+        model.load_state_dict(load_checkpoint(chkpt_fpath)[0])
         return model
 
     def load_state_dict(self, state: Mapping[str, object]):
-        unet, ce, te = {}, {}, {}
-        for k, v in state.items():
-            if k.startswith("ldm.eps_model."):
-                unet[k[len("ldm.eps_model."):]] = v
-            elif k.startswith("chord_enc."):
-                ce[k[len("chord_enc."):]] = v
-            elif k.startswith("txt_enc."):
-                te[k[len("txt_enc."):]] = v
-            elif k in ("ldm.alpha", "ldm.beta", "ldm.alpha_bar", "ldm.sigma2"):
-                continue  # recomputed from the params (latent_diffusion.py:90-103)
-            elif k.split(".")[0] in ("chord_dec", "pnotree_enc", "pnotree_dec"):
-                continue  # decode/debug-only modules
-            else:
-                raise RuntimeError(f"unexpected key in checkpoint: {k}")
+        from .checkpoint import split_state
+        unet, ce, te = split_state(state)
         self.ldm.eps_model.load_state_dict(unet)
         if self.chord_enc is not None and ce:
             self.chord_enc.load_state_dict(ce)

@@ -41,7 +41,7 @@ class DiffusionSampler:
         self.sample_offset = int(sample_offset)  # global index of this rank's first sample (multi-GPU sharding)
         self._draws = 0
         self._lib = _lib.load()
-        self._cfg_cache = None
+        self._tbuf = None
 
     # ---- noise ------------------------------------------------------------------------------------
     def randn(self, shape, device) -> torch.Tensor:
@@ -61,17 +61,18 @@ class DiffusionSampler:
             return self.model(x, t, c)
         elif uncond_scale == 0.0:
             return self.model(x, t, uncond_cond)
-        key = (c.data_ptr(), uncond_cond.data_ptr(), tuple(c.shape))
-        if self._cfg_cache is None or self._cfg_cache[0] != key:
-            self._cfg_cache = (key, torch.cat([uncond_cond, c]).contiguous())
-        eps2 = self.model(torch.cat([x, x]), torch.cat([t, t]), self._cfg_cache[1])
+        # re-concatenated on every call like the reference (sampler/__init__.py:69-74): [2B,n_cond,d_cond] is a few KB, and a
+        # cache keyed on addresses could serve a stale tensor after an in-place update or an allocator address reuse
+        eps2 = self.model(torch.cat([x, x]), torch.cat([t, t]), torch.cat([uncond_cond, c]))
         e_t = torch.empty_like(x)
         _lib.check(self._lib.pf_cfg_combine(eps2.data_ptr(), float(uncond_scale), e_t.data_ptr(), e_t.numel(),
                                             _lib.current_stream()), "pf_cfg_combine")
         return e_t
 
     def _eps(self, x, c, step, uncond_scale, uncond_cond, cond_concat):
-        t = torch.full((x.shape[0],), int(step), dtype=torch.long, device=x.device)
+        if self._tbuf is None or self._tbuf.shape[0] != x.shape[0] or self._tbuf.device != x.device:
+            self._tbuf = torch.empty(x.shape[0], dtype=torch.long, device=x.device)
+        t = self._tbuf.fill_(int(step))  # stream-ordered: the previous step's UNet has consumed the old value
         xin = x if cond_concat is None else torch.cat([x, cond_concat], dim=1)
         return self.get_eps(xin, t, c, uncond_scale=uncond_scale, uncond_cond=uncond_cond)
 
@@ -100,8 +101,9 @@ class SDFSampler(DiffusionSampler):
 
     @torch.no_grad()
     def p_sample(self, x, c, t, step: int, repeat_noise: bool = False, temperature: float = 1.0,
-                 uncond_scale: float = 1.0, uncond_cond=None, cond_concat=None):
-        """Returns (x_prev, x0, e_t) like the reference; x0 is recomputed by torch ops on request only."""
+                 uncond_scale: float = 1.0, uncond_cond=None, cond_concat=None, return_x0: bool = True):
+        """Returns (x_prev, x0, e_t) like the reference (sampler_sdf.py:80-171).  ``x0`` costs two extra elementwise
+        launches; the loops of this class (``sample`` / ``paint``) pass ``return_x0=False`` and get ``None`` for it."""
         step = int(step)
         e_t = self._eps(x, c, step, uncond_scale, uncond_cond, cond_concat)
         noise = None
@@ -115,7 +117,7 @@ class SDFSampler(DiffusionSampler):
         x_prev = torch.empty_like(x)
         _lib.check(self._lib.pf_ddpm_step(x.data_ptr(), e_t.data_ptr(), _lib.ptr(noise), None, None, None, C.byref(coef),
                                           x_prev.data_ptr(), x.numel(), _lib.current_stream()), "pf_ddpm_step")
-        x0 = coef.c_recip * x - coef.c_recipm1 * e_t
+        x0 = (coef.c_recip * x - coef.c_recipm1 * e_t) if return_x0 else None
         return x_prev, x0, e_t
 
     @torch.no_grad()
@@ -134,7 +136,7 @@ class SDFSampler(DiffusionSampler):
         x = x_last if x_last is not None else self.randn(shape, cond.device)
         for step in np.flip(self.time_steps)[t_start:]:
             x, _, _ = self.p_sample(x, cond, None, int(step), repeat_noise=repeat_noise, temperature=temperature,
-                                    uncond_scale=uncond_scale, uncond_cond=uncond_cond)
+                                    uncond_scale=uncond_scale, uncond_cond=uncond_cond, return_x0=False)
         return x
 
     @torch.no_grad()
@@ -152,7 +154,7 @@ class SDFSampler(DiffusionSampler):
             coef = self._coef(step)
             if orig is None:
                 x, _, _ = self.p_sample(x, cond, None, step, uncond_scale=uncond_scale, uncond_cond=uncond_cond,
-                                        cond_concat=cond_concat)
+                                        cond_concat=cond_concat, return_x0=False)
                 continue
             x_t = x
             for u in range(repaint_n):
@@ -209,6 +211,9 @@ class DDIMSampler(DiffusionSampler):
                 noise = noise.expand_as(x).contiguous()
             if temperature != 1.0:
                 noise = noise * temperature
+        if orig is not None and orig_noise is None:
+            # reference: q_sample(orig, index, noise=None) draws randn_like per step, after p_sample's draw (sampler_ddim.py:355-359)
+            orig_noise = self.randn(orig.shape, x.device)
         out = torch.empty_like(x)
         _lib.check(self._lib.pf_ddim_step(x.data_ptr(), e_t.data_ptr(), _lib.ptr(noise), _lib.ptr(orig), _lib.ptr(orig_noise),
                                           _lib.ptr(mask), C.byref(coef), out.data_ptr(), x.numel(), _lib.current_stream()),
@@ -254,7 +259,9 @@ class DDIMSampler(DiffusionSampler):
               uncond_cond=None, cond_concat=None, repaint_n: int = 1):
         x = x.contiguous()
         if orig is not None:
-            orig, mask, orig_noise = (v.contiguous().float() for v in (orig, mask, orig_noise))
+            assert mask is not None
+            orig, mask = orig.contiguous().float(), mask.contiguous().float()
+            orig_noise = None if orig_noise is None else orig_noise.contiguous().float()
         time_steps = np.flip(self.time_steps[: t_start + 1])
         for i, step in enumerate(time_steps):
             index = len(time_steps) - i - 1

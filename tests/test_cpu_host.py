@@ -166,7 +166,7 @@ def test_shard_plan_world_size_2_gloo(tmp_path):
     script.write_text(f'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, {REPO!r})
-from polyffusion_amd.dist import shard_range, broadcast_blob
+from polyffusion_amd.dist import shard_range, broadcast_blob, gather_rows, broadcast_int, ranks_seen
 dist.init_process_group("gloo")
 r, n = dist.get_rank(), dist.get_world_size()
 lo, hi = shard_range(37, r, n)
@@ -176,6 +176,14 @@ assert got[0][0] == 0 and got[-1][1] == 37 and all(got[i][1] == got[i + 1][0] fo
 blob = torch.arange(1000, dtype=torch.float32) if r == 0 else torch.zeros(1000)
 broadcast_blob(blob, src=0)
 assert blob.sum().item() == 499500.0
+# ragged end-of-run gather: 5 rows over 2 ranks (3 + 2), every rank ends with rows 0..4 in order
+a, b = shard_range(5, r, n)
+rows = torch.arange(a, b, dtype=torch.float32)[:, None, None].expand(b - a, 2, 3).contiguous()
+allrows = gather_rows(rows, 5, r, n)
+assert allrows.shape == (5, 2, 3) and torch.equal(allrows[:, 0, 0], torch.arange(5.)), allrows
+assert gather_rows(torch.zeros(0, 4) if r == 1 else torch.ones(1, 4), 1, r, n).shape == (1, 4)   # a rank with no rows
+assert broadcast_int(1234 + r) == 1234
+assert ranks_seen()[0] == n
 dist.barrier()
 if r == 0: print("OK", got)
 ''')
