@@ -64,7 +64,7 @@ class DiffusionSampler:
         # re-concatenated on every call like the reference (sampler/__init__.py:69-74): [2B,n_cond,d_cond] is a few KB, and a
         # cache keyed on addresses could serve a stale tensor after an in-place update or an allocator address reuse
         eps2 = self.model(torch.cat([x, x]), torch.cat([t, t]), torch.cat([uncond_cond, c]))
-        e_t = torch.empty_like(x)
+        e_t = torch.empty_like(eps2[: x.shape[0]])   # eps has out_channels; x may carry extra cond_concat channels
         _lib.check(self._lib.pf_cfg_combine(eps2.data_ptr(), float(uncond_scale), e_t.data_ptr(), e_t.numel(),
                                             _lib.current_stream()), "pf_cfg_combine")
         return e_t

@@ -113,7 +113,7 @@ def test_cli_from_run_directory(tmp_path, fmt):
     ck = run / "chkpts" / ("weights_best.pt" if fmt == "pt" else "last.ckpt")
     if fmt == "ckpt":
         os.remove(run / "params.yaml")      # a Lightning checkpoint carries its own params
-    argv = ["--chkpt_path", str(ck), "--synthetic", "--length", "2", "--ddim", "--ddim_steps", "3", "--uncond_scale", "2.0",
+    argv = ["--chkpt_path", str(ck), "--synthetic", "--length", "2", "--ddim", "--ddim_steps", "4", "--uncond_scale", "2.0",
             "--seed", "11", "--num_generate", "2", "--output_dir", str(out)]
     assert inference_sdf.main(argv) == 0
     npys = sorted(f for f in os.listdir(out) if f.endswith(".npy"))
