@@ -38,12 +38,21 @@ __device__ unsigned long long g_trace[8192];
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// bf16 elements between two halo rows of one plane.  A pixel is 40 elements (80 B: consecutive pixels of a row are
+// conflict-free for ds_read_b128); a fragment's 32 pixels span TWO tile rows, and with the natural row pitch TWIN*40 the second
+// row's 16-byte slots land on the banks of the first (2-way conflict on every A read: SQ_LDS_BANK_CONFLICT was 35 % of the LDS
+// cycles).  Padding the row pitch to a multiple of 256 B makes the two rows tile the 64 banks exactly.
+template <int KS, int STRIDE, int TWIN>
+constexpr int conv_bf3_row_pitch() {
+  return (KS != 1 && STRIDE == 1) ? (TWIN * 40 + 127) / 128 * 128 : TWIN * 40;
+}
+
 // LDS bytes of one wave group: the main loop's halo image + weight ring, or the fused 1x1 phase's double buffers
 template <int KS, int STRIDE, int TH, int TW, int BN, bool SKIP>
 constexpr size_t conv_bf3_group_lds() {
   constexpr int THIN = (TH - 1) * STRIDE + KS, TWIN = (TW - 1) * STRIDE + KS;
   constexpr int NABUF = (KS == 1) ? 2 : 1, WRING = (KS == 3) ? 3 : 2;
-  constexpr size_t main_b = (size_t)(2 * NABUF * THIN * TWIN * 40 + WRING * 8 * BN * 8) * 2;
+  constexpr size_t main_b = (size_t)(2 * NABUF * THIN * conv_bf3_row_pitch<KS, STRIDE, TWIN>() + WRING * 8 * BN * 8) * 2;
   constexpr size_t skip_b = SKIP ? (size_t)(2 * 2 * TH * TW * 40 + 2 * 8 * BN * 8) * 2 : 0;
   return main_b > skip_b ? main_b : skip_b;
 }
@@ -75,7 +84,9 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   constexpr int WM = BM / NWM, WN = BN / 2;
   constexpr int FM = WM / 32, FN = WN / 32;
   constexpr int PAD = (KS == 3) ? 1 : 0;   // KS == 2 (parity-folded upsampling conv): the pad depends on the parity, see iy0
-  constexpr int APLANE = NABUF * NPIX * PITCH;  // bf16 elements per A plane
+  constexpr int RP = conv_bf3_row_pitch<KS, STRIDE, TWIN>();   // bf16 elements per halo row (padded, see conv_bf3_row_pitch)
+  constexpr int ABUF = THIN * RP;               // bf16 elements per halo image
+  constexpr int APLANE = NABUF * ABUF;          // bf16 elements per A plane
   static_assert(TOTW % NT == 0 && FM >= 1 && FN >= 1, "bad tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
@@ -187,12 +198,13 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     for (int i = 0; i < NA; ++i) transformPiece(i);
   };
   auto writeA = [&](int buf) {
-    const int base = buf * (NPIX * PITCH) + (tid / KQ) * PITCH + c4 * 4;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      if (tid / KQ + i * PSTEP < NPIX) {
-        *reinterpret_cast<bf16x4*>(sAh + base + i * PSTEP * PITCH) = qh[i];
-        *reinterpret_cast<bf16x4*>(sAl + base + i * PSTEP * PITCH) = ql[i];
+      const int pix = tid / KQ + i * PSTEP;
+      if (pix < NPIX) {
+        const int o = buf * ABUF + (pix / TWIN) * RP + (pix % TWIN) * PITCH + c4 * 4;
+        *reinterpret_cast<bf16x4*>(sAh + o) = qh[i];
+        *reinterpret_cast<bf16x4*>(sAl + o) = ql[i];
       }
     }
   };
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   for (int fm = 0; fm < FM; ++fm) {
     const int pp = wm * WM + fm * 32 + (lane & 31);
     const int py = pp / TW, px = pp % TW;
-    hbase[fm] = ((py * STRIDE) * TWIN + px * STRIDE) * PITCH + 8 * (lane >> 5);
+    hbase[fm] = (py * STRIDE) * RP + (px * STRIDE) * PITCH + 8 * (lane >> 5);
   }
   const int wbase = ((lane >> 5) * 2 * BN + wn * WN + (lane & 31)) * 8;
 
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       const int nchunk1 = min(chunk + 1, nchunk - 1);
       loadW(nchunk1, 0);
       loadA(nchunk1);
-      const int aoff = (chunk & 1) * (NPIX * PITCH);
+      const int aoff = (chunk & 1) * ABUF;
       const __bf16* cW = sW + (chunk & 1) * (TOTW * 8) + wbase;
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
@@ -322,63 +334,152 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     const unsigned wb = (unsigned)(size_t)(__attribute__((address_space(3))) __bf16*)(sW + wbase);
     constexpr int ALO = APLANE * 2;          // byte offset of the lo plane
     constexpr int WSLOT = TOTW * 16;         // bytes per ring slot
-    static_assert(ALO + (2 * TWIN + 2) * PITCH * 2 + 64 < 65536 && WRING * WSLOT < 65536, "LDS immediates must fit 16 bits");
+    static_assert(ALO + (2 * RP + 2 * PITCH) * 2 + 64 < 65536 && WRING * WSLOT < 65536, "LDS immediates must fit 16 bits");
     // AOFF = halo pixel offset of a tap (elements), S = K step inside the tap, SLOT = ring slot
-#define LD_AL(AOFF, S) static_for<0, FM>([&](auto i) { al[i.value] = lds_read128<ALO + ((AOFF) + (S) * 16) * 2>(abase[i.value]); })
-#define LD_AH(AOFF, S) static_for<0, FM>([&](auto i) { ah[i.value] = lds_read128<((AOFF) + (S) * 16) * 2>(abase[i.value]); })
-#define LD_BH(SLOT, S) static_for<0, FN>([&](auto i) { bh[i.value] = lds_read128<(SLOT) * WSLOT + ((4 * (S)) * BN + i.value * 32) * 16>(wb); })
-#define LD_BL(SLOT, S) static_for<0, FN>([&](auto i) { bl[i.value] = lds_read128<(SLOT) * WSLOT + ((4 * (S) + 1) * BN + i.value * 32) * 16>(wb); })
-    auto X = [&]() {
-#pragma unroll
-      for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
-    };
-    auto Z = [&]() {
-#pragma unroll
-      for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
-    };
-    auto Y = [&]() {
-#pragma unroll
-      for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
-    };
+    // single-fragment reads (I = fragment index); the *_ALL forms read a whole operand set
+#define LD_AL1(I, AOFF, S) al[I] = lds_read128<ALO + ((AOFF) + (S) * 16) * 2>(abase[I])
+#define LD_AH1(I, AOFF, S) ah[I] = lds_read128<((AOFF) + (S) * 16) * 2>(abase[I])
+#define LD_BH1(I, SLOT, S) bh[I] = lds_read128<(SLOT) * WSLOT + ((4 * (S)) * BN + (I) * 32) * 16>(wb)
+#define LD_BL1(I, SLOT, S) bl[I] = lds_read128<(SLOT) * WSLOT + ((4 * (S) + 1) * BN + (I) * 32) * 16>(wb)
+#define LD_AL(AOFF, S) static_for<0, FM>([&](auto i) { LD_AL1(i.value, AOFF, S); })
+#define LD_AH(AOFF, S) static_for<0, FM>([&](auto i) { LD_AH1(i.value, AOFF, S); })
+#define LD_BH(SLOT, S) static_for<0, FN>([&](auto i) { LD_BH1(i.value, SLOT, S); })
+#define LD_BL(SLOT, S) static_for<0, FN>([&](auto i) { LD_BL1(i.value, SLOT, S); })
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define FENCE() asm volatile("" ::: "memory")
+    // An in-order wave hides at most ~5 single-issue instructions behind one 32-cycle MFMA: everything that is not an MFMA
+    // (fragment reads, the next halo's loads and its normalise/activate/split arithmetic, the weight-ring refill) is therefore
+    // cut into small pieces and dealt out BETWEEN the individual MFMAs instead of sitting in blocks between MFMA groups
+    // (measured on the block form: the halo arithmetic alone, although placed "in the shadow" of a group, cost 9-14 %).
+    // An MFMA group walks its G = FM*FN accumulators; `f(fm, fn)` runs right after the MFMA on acc[fm][fn] has issued.
+    constexpr int G = FM * FN;
+    auto GX = [&](auto&& f) {   // a_lo x w_hi, fm outer: al[fm] is free after its last fn
+      static_for<0, FM>([&](auto fm) { static_for<0, FN>([&](auto fn) {
+        acc[fm.value][fn.value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm.value], bh[fn.value], acc[fm.value][fn.value], 0, 0, 0);
+        SB(); f(fm, fn); SB(); }); });
+    };
+    auto GZ = [&](auto&& f) {   // a_hi x w_hi, fn outer: bh[fn] is free after its last fm
+      static_for<0, FN>([&](auto fn) { static_for<0, FM>([&](auto fm) {
+        acc[fm.value][fn.value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm.value], bh[fn.value], acc[fm.value][fn.value], 0, 0, 0);
+        SB(); f(fm, fn); SB(); }); });
+    };
+    auto GY = [&](auto&& f) {   // a_hi x w_lo, fm outer: ah[fm] is free after its last fn, the w_lo set after the last MFMA
+      static_for<0, FM>([&](auto fm) { static_for<0, FN>([&](auto fn) {
+        acc[fm.value][fn.value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm.value], bl[fn.value], acc[fm.value][fn.value], 0, 0, 0);
+        SB(); f(fm, fn); SB(); }); });
+    };
+    // ---- the non-MFMA work of a chunk, in pieces
+    auto loadApiece = [&](int chunk, int i) {   // piece i < NA: one halo float4; i == NA: the chunk's GroupNorm scale/shift
+      const int cg = (cbeg + chunk) * BK;
+      const float* src; int cs, co;
+      if (cg < p.c0) { src = p.x0; cs = p.c0; co = cg; } else { src = p.x1; cs = p.c1; co = cg - p.c0; }
+      // Issued as inline asm, hidden from hipcc's wait-count pass: with direct-to-LDS loads in flight the compiler waits
+      // vmcnt(0) before the first use of an ordinary load's result, which drained the whole weight ring once per chunk.
+      // The destination registers are read by transformSub only after the hand-placed vmcnt wait below.
+      if (i < NA) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[i]) : "v"(src + co + (unsigned)(max(poff[i], 0) * cs + c4 * 4)));
+      else if (PRO == 1 || PRO == 2) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vsc) : "v"(p.sc + (size_t)b * cin + cg + c4 * 4));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vsh) : "v"(p.sh + (size_t)b * cin + cg + c4 * 4));
+      }
+    };
+    // transform of piece i in four sub-steps: elements {0,1}, {2,3} in place, then the hi plane, then the lo plane
+    auto transformSub = [&](int i, int sub) {
+      if (sub < 2) {
+#pragma unroll
+        for (int e = 2 * sub; e < 2 * sub + 2; ++e) {
+          float v = ra[i][e];
+          if (poff[i] < 0) v = 0.f;
+          else if (PRO != 0) { v = v * vsc[e] + vsh[e]; if (PRO == 1) v = silu_f(v); }
+          ra[i][e] = v;
+        }
+      } else if (sub == 2) {
+        qh[i] = __builtin_convertvector(ra[i], bf16x4);
+      } else {
+        ql[i] = __builtin_convertvector(ra[i] - __builtin_convertvector(qh[i], f32x4), bf16x4);
+      }
+    };
+    auto gldsWpiece = [&](int chunk, int tap, int buf, int j) {
+      const size_t toff = ((size_t)(q * TAPS + tap) * K8 + (size_t)(cbeg + chunk) * 4) * wrow;
+      __bf16* l = sW + buf * (TOTW * 8) + (wave * 64 + j * NT) * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw0 + toff + (size_t)j * (NT / (2 * BN)) * wrow),
+                                       (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    };
     LD_AL(0, 0); LD_BH(0, 0); LD_AH(0, 0); LD_BL(0, 0);
     // The loop body is branch-free around the MFMAs (tail iterations prefetch clamped tiles and read fragments that are
-    // never used).  LDS reads complete in issue order, so "at most FM+FN reads outstanding" is the wait before every group
-    // in the steady state: the reads issued after the fragments a group needs are always exactly one a-set and one w-set.
+    // never used).  LDS reads complete in issue order and are issued in the fixed order a_lo, w_hi, a_hi, w_lo (each set right
+    // after its last reader), so "at most FM+FN reads outstanding" is the wait before every group in the steady state.
     for (int chunk = 0; chunk < nchunk; ++chunk) {
       const bool has_next = chunk + 1 < nchunk;
+      const int chunkn = min(chunk + 1, nchunk - 1);
       static_for<0, TAPS>([&](auto tapc) {
         constexpr int tap = decltype(tapc)::value;
-        constexpr int aoff = ((tap / KS) * TWIN + (tap % KS)) * PITCH;
-        constexpr int aoff1 = (((tap + 1) / KS) * TWIN + ((tap + 1) % KS)) * PITCH;
+        constexpr int aoff = (tap / KS) * RP + (tap % KS) * PITCH;
+        constexpr int aoff1 = ((tap + 1) / KS) * RP + ((tap + 1) % KS) * PITCH;
         constexpr int slot = tap % WRING, slotn = (tap + 1) % WRING;   // TAPS % WRING == 0: a tile's ring slot is tap % WRING
+        // which halo piece this tap transforms (spread over the middle taps: 2..7 of 9, 1..2 of 4), -1 = none
+        constexpr int T0 = TAPS >= 9 ? 2 : 1, TSPAN = TAPS - 1 - T0;
+        // filler after MFMA number k of the tap (k = 0..6G-1: groups X0 Z0 Y0 X1 | barrier | Z1 Y1)
+        int c2 = chunk + (tap + WRING) / TAPS, t2 = (tap + WRING) % TAPS;     // the tile that refills this tap's ring slot
+        if (c2 >= nchunk) { c2 = nchunk - 1; t2 = TAPS - 1; }
+        auto filler = [&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          if constexpr (tap == 0 && k < 3 * G) {       // next chunk's halo loads over X0 Z0 Y0 (all before this tap's barrier)
+            static_for<0, NA + 1>([&](auto ic) {
+              constexpr int i = decltype(ic)::value;
+              if constexpr (k == (i * 3 * G) / (NA + 1)) { if (i < NA || PRO != 0) loadApiece(chunkn, i); }
+            });
+          }
+          if constexpr (k >= 3 * G && k < 4 * G) {     // X1: this tap's share of the halo arithmetic
+            if (has_next) {
+              static_for<0, NA>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (tap == T0 + (i * TSPAN) / NA) {
+                  static_for<0, 4>([&](auto sc_) {
+                    constexpr int sub = decltype(sc_)::value;
+                    if constexpr (k - 3 * G == (sub * G) / 4) {
+                      if constexpr (i == 0 && sub == 0) {
+                        // first use of the halo registers in this chunk: the loads issued in tap 0 are older than the WRING-1
+                        // weight tiles issued since (tap T0's own refill comes after this group)
+                        static_assert(T0 + 1 == WRING, "the count below assumes WRING-1 tiles were issued between tap 0 and tap T0");
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WRING - 1) * NW) : "memory");
+                        SB();
+                      }
+                      transformSub(i, sub);
+                    }
+                  });
+                }
+              });
+            }
+          }
+          if constexpr (k >= 4 * G && k < 5 * G) {     // Z1 (after the barrier): refill the ring slot this tap has finished with
+            static_for<0, NW>([&](auto jc) {
+              constexpr int j = decltype(jc)::value;
+              if constexpr (k - 4 * G == (j * G) / NW) gldsWpiece(c2, t2, slot, j);
+            });
+          }
+        };
         TR();
         SB();
         // outstanding on entry: a_lo, w_hi, a_hi, w_lo of (tap, step 0) in that order - after a chunk boundary a_lo, a_hi
         lgkm_wait<(tap == 0) ? FM : FM + FN>(); SB();
-        X(); SB(); LD_AL(aoff, 1);
-        if (tap == 0) loadA(min(chunk + 1, nchunk - 1));     // next chunk's halo loads, in the MFMA shadow
-        SB();
+        GX([&](auto fm, auto fn) {
+          if constexpr (fn.value == FN - 1) LD_AL1(fm.value, aoff, 1);
+          filler(std::integral_constant<int, 0 * G + fm.value * FN + fn.value>{});
+        });
         lgkm_wait<(tap == 0) ? FM : FM + FN>(); SB();
-        Z(); SB(); LD_BH(slot, 1); SB();
+        GZ([&](auto fm, auto fn) {
+          if constexpr (fm.value == FM - 1) LD_BH1(fn.value, slot, 1);
+          filler(std::integral_constant<int, 1 * G + fn.value * FM + fm.value>{});
+        });
         lgkm_wait<FM + FN>(); SB();
-        Y();
-        if (has_next) {   // the next halo's normalise/activate/split arithmetic, spread over the middle taps (2..7 of 9, 1..2 of 4)
-          constexpr int T0 = TAPS >= 9 ? 2 : 1, TSPAN = TAPS - 1 - T0;
-#pragma unroll
-          for (int i = 0; i < NA; ++i)
-            if (tap == T0 + (i * TSPAN) / NA) transformPiece(i);
-        }
-        SB(); LD_AH(aoff, 1); LD_BL(slot, 1); SB();
+        GY([&](auto fm, auto fn) {
+          if constexpr (fn.value == FN - 1) LD_AH1(fm.value, aoff, 1);
+          if constexpr (fm.value == FM - 1 && fn.value == FN - 1) LD_BL(slot, 1);
+          filler(std::integral_constant<int, 2 * G + fm.value * FN + fn.value>{});
+        });
         lgkm_wait<FM + FN>(); SB();
-        X(); SB();
+        GX([&](auto fm, auto fn) { filler(std::integral_constant<int, 3 * G + fm.value * FN + fn.value>{}); });
+        SB();
         TR();
         // the next tile must be complete.  This thread's vector loads issued after it are the WRING-2 newer weight tiles and -
         // while tile it+1 was issued before this chunk's tap 0 - the NAL halo loads.  lgkmcnt(0): all reads of this slot done.
@@ -386,28 +487,42 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
         TR();
         __builtin_amdgcn_s_barrier();
         FENCE();
+        SB();   // nothing of Z1 may be hoisted above the wait: its a_hi / w_lo fragments are only now guaranteed to have landed
         TR();
-        {
-          int c2 = chunk + (tap + WRING) / TAPS, t2 = (tap + WRING) % TAPS;
-          if (c2 >= nchunk) { c2 = nchunk - 1; t2 = TAPS - 1; }
-          gldsW(c2, t2, slot);
-        }
         if constexpr (tap == TAPS - 1) {
           if (has_next) writeA(0);
           SB();
-          Z(); SB(); LD_BH(slotn, 0); SB();
-          Y(); SB(); LD_BL(slotn, 0);
+          GZ([&](auto fm, auto fn) {
+            if constexpr (fm.value == FM - 1) LD_BH1(fn.value, slotn, 0);
+            filler(std::integral_constant<int, 4 * G + fn.value * FM + fm.value>{});
+          });
+          GY([&](auto fm, auto fn) {
+            if constexpr (fm.value == FM - 1 && fn.value == FN - 1) LD_BL(slotn, 0);
+            filler(std::integral_constant<int, 5 * G + fm.value * FN + fn.value>{});
+          });
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           FENCE();
           LD_AL(0, 0); LD_AH(0, 0); SB();
         } else {
-          LD_AL(aoff1, 0); SB();
-          Z(); SB(); LD_BH(slotn, 0); SB();
-          Y(); SB(); LD_AH(aoff1, 0); LD_BL(slotn, 0); SB();
+          // the A reads of the next tap do not depend on the barrier but keep the fixed issue order a_lo, w_hi, a_hi, w_lo
+          GZ([&](auto fm, auto fn) {
+            if constexpr (fn.value == 0) LD_AL1(fm.value, aoff1, 0);
+            if constexpr (fm.value == FM - 1) LD_BH1(fn.value, slotn, 0);
+            filler(std::integral_constant<int, 4 * G + fn.value * FM + fm.value>{});
+          });
+          GY([&](auto fm, auto fn) {
+            if constexpr (fn.value == FN - 1) LD_AH1(fm.value, aoff1, 0);
+            if constexpr (fm.value == FM - 1 && fn.value == FN - 1) LD_BL(slotn, 0);
+            filler(std::integral_constant<int, 5 * G + fm.value * FN + fn.value>{});
+          });
         }
       });
     }
+#undef LD_AL1
+#undef LD_AH1
+#undef LD_BH1
+#undef LD_BL1
 #undef LD_AL
 #undef LD_AH
 #undef LD_BH
@@ -415,6 +530,11 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
 #undef FENCE
 #undef SB
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // drain the clamped tail prefetches before the workgroup retires
+    // ... and before the registers of the hidden halo loads (last issued in the final chunk's tap 0, never consumed) can be reused
+#pragma unroll
+    for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(ra[i]));
+    asm volatile("" : "+v"(vsc), "+v"(vsh));
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   if constexpr (SKIP) {
@@ -616,9 +736,10 @@ static int dispatch_tile3(ConvP& p, int tile, hipStream_t s) {
       // no more tiles than CUs (and an even number of K chunks): two wave groups per workgroup split K (see the kernel)
       static const bool no_kg = getenv("PF_NO_KGROUPS") != nullptr;   // experiment hook
       const int blocks = p.B * cdiv(p.Hout, tile == 2 ? 4 : 8) * cdiv(p.Wout, 16) * cdiv(p.Npad, tile == 0 ? 128 : 64);
-      const bool kg2 = !no_kg && tile == 2 && p.ksplit == 1 && blocks <= 256 && ((p.c0 + p.c1) / 32) % 2 == 0 && (!p.sw || ((p.sc0 + p.sc1) / 32) % 2 == 0);
-      // (measured: splitting the 128x128 tile the same way is neutral - its two waves per SIMD already cover each other)
+      static const bool kg_wide = getenv("PF_KG_WIDE") != nullptr;   // experiment hook: the 128x128 tile split the same way
+      const bool kg2 = !no_kg && (tile == 2 || (kg_wide && tile == 0)) && p.ksplit == 1 && blocks <= 256 && ((p.c0 + p.c1) / 32) % 2 == 0 && (!p.sw || ((p.sc0 + p.sc1) / 32) % 2 == 0);
       if (kg2 && tile == 2) return p.sw ? launch3_cfg<3, 1, false, 4, 16, 64, 1, 2, true, 2>(p, s) : launch3_cfg<3, 1, false, 4, 16, 64, 1, 2, false, 2>(p, s);
+      if (kg2 && tile == 0) return p.sw ? launch3_cfg<3, 1, false, 8, 16, 128, 1, 2, true, 2>(p, s) : launch3_cfg<3, 1, false, 8, 16, 128, 1, 2, false, 2>(p, s);
       if (p.sw) {   // fused skip projection: only the ResBlock second-conv configurations are instantiated
         if (tile == 0) return launch3_cfg<3, 1, false, 8, 16, 128, 1, 2, true>(p, s);
         if (tile == 1) return launch3_cfg<3, 1, false, 8, 16, 64, 1, 2, true>(p, s);

@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""Timing experiments on throw-away variants of a kernel source (results are WRONG by construction; only the
+timing matters).  Builds build/exp/libpfhip_<name>.so from a patched copy of one .hip file + the in-tree objects.
+usage: python tools/exp_variant.py <file.hip> <name> '<old>' '<new>' ['<old2>' '<new2>' ...]"""
+import os, subprocess, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "polyffusion_amd", "csrc")
+f, name, subs = sys.argv[1], sys.argv[2], sys.argv[3:]
+src = open(os.path.join(CSRC, f)).read()
+for old, new in zip(subs[0::2], subs[1::2]):
+    assert src.count(old) >= 1, f"pattern not found: {old[:60]}"
+    src = src.replace(old, new)
+out_dir = os.path.join(REPO, "build", "exp")
+os.makedirs(out_dir, exist_ok=True)
+patched = os.path.join(CSRC, f"_exp_{name}_{f}")   # must sit next to its headers
+open(patched, "w").write(src)
+obj = os.path.join(out_dir, f"{name}.o")
+try:
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-c", patched, "-o", obj])
+finally:
+    os.remove(patched)
+objs = [os.path.join(CSRC, o) for o in sorted(os.listdir(CSRC)) if o.endswith(".o") and o != f.replace(".hip", ".o")]
+so = os.path.join(out_dir, f"libpfhip_{name}.so")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, obj] + objs)
+print(so)
