@@ -97,10 +97,12 @@ def cpu_baseline(params, reps=3):
         return time.perf_counter() - t0
 
     default_threads = torch.get_num_threads()
-    sweep = sorted({n for n in (32, 64, 128, ncpu) if n <= ncpu} | {default_threads})
+    # oneDNN's convolutions stop scaling long before a 256-thread host is full (measured on the GPU box: 32 threads 0.31 steps/s,
+    # 64: 0.20, 128: 0.11, all 256: 0.008), so the sweep stays at or below 128 and the best count is what gets reported
+    sweep = sorted({n for n in (16, 32, 64, 128) if n <= ncpu}) or [ncpu]
     probes = {}
     with torch.no_grad():
-        torch.set_num_threads(default_threads)
+        torch.set_num_threads(min(32, ncpu))
         one_step()                                   # warm-up: a full step on the same inputs
         for n in sweep:
             torch.set_num_threads(n)
@@ -149,6 +151,42 @@ def profiled_pass(unet, step_fn, x, t_step, n_steps, precision, dump=False):
     return x, agg
 
 
+def small_batch_lines(model, params, steps, precision):
+    """Secondary lines: the launch-bound regime.  Batch 1 is what the reference CLI's --autoreg runs (one 8-bar segment per
+    sampling run), batch 8 the per-GPU shape of BASELINE config 5 (8 songs per GPU).  Each is timed through
+    SDFSampler.paint() - the RePaint loop body with orig/mask, exactly what Experiments.predict drives - once eagerly (about 220
+    host-side launches per step) and once as replays of one captured hipGraph step (device-resident step state)."""
+    import time as _t
+    dev = torch.device("cuda", torch.cuda.current_device())
+    res = {}
+    for B in (1, 8):
+        chords = torch.from_numpy(synth.chords(B, seed=777)).to(dev)
+        cond = model._encode_chord(chords)
+        shape = (B, params.out_channels, params.img_h, params.img_w)
+        z = torch.zeros(shape, device=dev)
+        mask = torch.zeros(shape, device=dev)
+        mask[:, :, : params.img_h // 2] = 1        # the autoregressive half-overlap: first half known
+        line = {}
+        for mode in ("eager", "graph"):
+            s = SDFSampler(model.ldm, seed=3, graph=(mode == "graph"))
+            x = s.randn(shape, dev)
+            s.paint(x, cond, 3, orig=z, mask=mask)                       # warm-up (tile instantiation, workspace)
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            s.paint(x, cond, steps, orig=z, mask=mask)                   # steps+1 reverse steps
+            torch.cuda.synchronize()
+            wall = _t.perf_counter() - t0
+            line[mode + "_steps_per_s"] = round((steps + 1) / wall, 2)
+            if mode == "graph":
+                e0, e1, n = s.last_replay
+                line["graph_replay_ms_per_step"] = round(e0.elapsed_time(e1) / n, 4)
+                line["graph_note"] = "wall time includes capturing + instantiating the graph once per paint() call"
+        res[f"batch{B}"] = line
+    res["precision"] = precision
+    res["steps"] = steps + 1
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +195,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=2, help="profiled steps for the roofline object (0 disables)")
     ap.add_argument("--fp32-steps", type=int, default=10, help="steps of the exact-fp32-MFMA mode measured in the same run (0 disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--small-batch-steps", type=int, default=40, help="reverse steps of the batch-1 / batch-8 eager-vs-hipGraph lines (0 disables)")
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="arithmetic of the dense contractions: exact fp32 MFMA, or the error-compensated bf16x3 split")
     ap.add_argument("--dump-launches", action="store_true", help="print one line per kernel launch of a profiled step (stderr)")
@@ -267,6 +306,8 @@ def main():
                 fp32["conv3x3_frac_of_157"] = round(agg32[0][2] / (agg32[0][1] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
         unet.set_precision(args.precision)
         out["fp32_mode"] = fp32
+    if rank == 0 and args.small_batch_steps > 0:
+        out["small_batch"] = small_batch_lines(model, params, args.small_batch_steps, args.precision)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params)
     if rank == 0:

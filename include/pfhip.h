@@ -112,6 +112,31 @@ int pf_ddim_step(const float* x, const float* eps, const float* noise, const flo
  * elem_offset = index of out[0] in the global (unsharded) tensor. */
 int pf_randn(float* out, size_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, void* stream);
 
+/* ---- replayable reverse step: everything that changes from one step to the next - the table row, the
+ * time-step value fed to the denoiser, the noise draw counter - lives in a small device-resident state, so ONE captured
+ * hipGraph of {begin, randn, pf_unet_forward, randn, step, end} is replayed for every step of the loop.  `table` is the
+ * per-step coefficient table on the device (one pf_ddpm_coef / pf_ddim_coef per row), `time_steps` the DDIM tau table
+ * (int32 per row; NULL: the row index itself is the time step, as in the DDPM sampler). */
+typedef struct pf_step_state { int64_t index; uint64_t draws; } pf_step_state;
+int pf_step_state_set(pf_step_state* dev_state, int64_t index, uint64_t draws, void* stream);
+int pf_step_begin(const pf_step_state* dev_state, const int32_t* time_steps, int64_t* t_out, int batch, void* stream);
+int pf_step_end(pf_step_state* dev_state, int draws_used, void* stream);          /* index -= 1; draws += draws_used */
+int pf_randn_dev(float* out, size_t n, uint64_t seed, const pf_step_state* dev_state, int slot, uint64_t elem_offset, void* stream);
+int pf_ddpm_step_dev(const float* x, const float* eps, const float* noise_p, const float* noise_q, const float* orig,
+                     const float* mask, const pf_ddpm_coef* table, const pf_step_state* dev_state, float* x_out, size_t n, void* stream);
+int pf_ddim_step_dev(const float* x, const float* eps, const float* noise, const float* orig, const float* orig_noise,
+                     const float* mask, const pf_ddim_coef* table, const pf_step_state* dev_state, float* x_out, size_t n, void* stream);
+
+/* ---- weight broadcast over RCCL / xGMI.  The path has ONE exchange: rank 0 ships the packed weight
+ * blob at start-up; the step loop has no collective.  librccl.so is opened on first use (dlopen), so a single-GPU process
+ * never loads it.  `unique_id` is the 128-byte ncclUniqueId: rank 0 obtains it with pf_comm_unique_id and hands it to the
+ * other ranks out of band (file / TCP store), exactly like an ncclUniqueId. */
+typedef struct pf_comm pf_comm;
+int pf_comm_unique_id(void* unique_id_out128);
+int pf_comm_init(const void* unique_id128, int rank, int nranks, pf_comm** out);
+int pf_comm_bcast(pf_comm* comm, void* dev_buf, size_t bytes, int root, void* stream);
+int pf_comm_destroy(pf_comm* comm);
+
 /* ---- output step: generated onset/sustain image -> note durations ----
  * Replaces the triple Python loop of utils.py:240-269 (prmat2c_to_prmat) and the note extraction of
  * utils.py:433-476 (prmat2c_to_midi_file): dur[n][t][key] = length in steps of the note that starts at (t, key), 0 where no

@@ -79,6 +79,16 @@ SIGNATURES = {
     "pf_axpby": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_ddim_step": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(DdimCoef), C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_randn": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "pf_step_state_set": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
+    "pf_step_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pf_step_end": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "pf_randn_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]),
+    "pf_ddpm_step_dev": (C.c_int, [C.c_void_p] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_ddim_step_dev": (C.c_int, [C.c_void_p] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pf_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "pf_comm_bcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "pf_comm_destroy": (C.c_int, [C.c_void_p]),
     "pf_prmat2c_durations": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pf_encoder_create": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_void_p)]),
     "pf_encoder_destroy": (None, [C.c_void_p]),

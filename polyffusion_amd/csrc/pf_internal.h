@@ -82,6 +82,14 @@ int launch_axpby(const float* x, const float* y, float a, float b, float* out, s
 int launch_ddim_step(const float* x, const float* eps, const float* noise, const float* orig, const float* orig_noise,
                      const float* mask, const pf_ddim_coef& c, float* out, size_t n, hipStream_t s);
 int launch_randn(float* out, size_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, hipStream_t s);
+int launch_randn_dev(float* out, size_t n, uint64_t seed, const pf_step_state* st, int slot, uint64_t elem_offset, hipStream_t s);
+int launch_ddpm_step_dev(const float* x, const float* eps, const float* noise_p, const float* noise_q, const float* orig,
+                         const float* mask, const pf_ddpm_coef* table, const pf_step_state* st, float* out, size_t n, hipStream_t s);
+int launch_ddim_step_dev(const float* x, const float* eps, const float* noise, const float* orig, const float* orig_noise,
+                         const float* mask, const pf_ddim_coef* table, const pf_step_state* st, float* out, size_t n, hipStream_t s);
+int launch_step_state_set(pf_step_state* st, int64_t index, uint64_t draws, hipStream_t s);
+int launch_step_begin(const pf_step_state* st, const int* time_steps, int64_t* t_out, int batch, hipStream_t s);
+int launch_step_end(pf_step_state* st, int draws_used, hipStream_t s);
 
 // encoder kernels
 int launch_gru_gates(const float* gi, int ld_gi, const float* gh, float* h, int ld_h, int batch, int hidden, hipStream_t s);

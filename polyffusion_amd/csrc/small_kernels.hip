@@ -359,24 +359,41 @@ int launch_cfg_combine(const float* eps2, float scale, float* eps, size_t n, hip
   return PF_OK;
 }
 
+__device__ __forceinline__ float ddpm_update(float xv, float ev, const float* np, const float* nq, const float* orig, const float* mask,
+                                             const pf_ddpm_coef& c, size_t i) {
+  // same operation order as the reference (each product rounded, then the sum)
+  const float x0 = __fsub_rn(__fmul_rn(c.c_recip, xv), __fmul_rn(c.c_recipm1, ev));
+  const float mean = __fadd_rn(__fmul_rn(c.c_x0, x0), __fmul_rn(c.c_xt, xv));
+  float xu = mean;
+  if (np) xu = __fadd_rn(mean, __fmul_rn(c.sigma, np[i]));
+  if (orig) {
+    float xk = __fmul_rn(c.sqrt_ab, orig[i]);
+    if (nq) xk = __fadd_rn(xk, __fmul_rn(c.sqrt_1mab, nq[i]));
+    const float m = mask[i];
+    xu = __fadd_rn(__fmul_rn(xk, m), __fmul_rn(xu, 1.0f - m));
+  }
+  return xu;
+}
 __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ np,
                                  const float* __restrict__ nq, const float* __restrict__ orig, const float* __restrict__ mask,
                                  pf_ddpm_coef c, float* __restrict__ out, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float xv = x[i];
-    // same operation order as the reference (each product rounded, then the sum)
-    const float x0 = __fsub_rn(__fmul_rn(c.c_recip, xv), __fmul_rn(c.c_recipm1, eps[i]));
-    const float mean = __fadd_rn(__fmul_rn(c.c_x0, x0), __fmul_rn(c.c_xt, xv));
-    float xu = mean;
-    if (np) xu = __fadd_rn(mean, __fmul_rn(c.sigma, np[i]));
-    if (orig) {
-      float xk = __fmul_rn(c.sqrt_ab, orig[i]);
-      if (nq) xk = __fadd_rn(xk, __fmul_rn(c.sqrt_1mab, nq[i]));
-      const float m = mask[i];
-      xu = __fadd_rn(__fmul_rn(xk, m), __fmul_rn(xu, 1.0f - m));
-    }
-    out[i] = xu;
-  }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = ddpm_update(x[i], eps[i], np, nq, orig, mask, c, i);
+}
+// the same update with the coefficients read from a device table row named by the device-resident step state (graph replay)
+__global__ void ddpm_step_dev_kernel(const float* x, const float* __restrict__ eps, const float* __restrict__ np,
+                                     const float* __restrict__ nq, const float* __restrict__ orig, const float* __restrict__ mask,
+                                     const pf_ddpm_coef* __restrict__ table, const pf_step_state* __restrict__ st, float* out, size_t n) {
+  const pf_ddpm_coef c = table[st->index];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = ddpm_update(x[i], eps[i], np, nq, orig, mask, c, i);
+}
+int launch_ddpm_step_dev(const float* x, const float* eps, const float* noise_p, const float* noise_q, const float* orig,
+                         const float* mask, const pf_ddpm_coef* table, const pf_step_state* st, float* out, size_t n, hipStream_t s) {
+  PF_REQUIRE(x && eps && out && table && st && n > 0 && (!orig || mask), "ddpm_step_dev: bad arguments");
+  hipLaunchKernelGGL(ddpm_step_dev_kernel, ew_grid(n), dim3(256), 0, s, x, eps, noise_p, noise_q, orig, mask, table, st, out, n);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
 }
 int launch_ddpm_step(const float* x, const float* eps, const float* noise_p, const float* noise_q, const float* orig,
                      const float* mask, const pf_ddpm_coef& c, float* out, size_t n, hipStream_t s) {
@@ -398,21 +415,63 @@ int launch_axpby(const float* x, const float* y, float a, float b, float* out, s
   return PF_OK;
 }
 
+__device__ __forceinline__ float ddim_update(float xv, float e, const float* noise, const float* orig, const float* on, const float* mask,
+                                             const pf_ddim_coef& c, size_t i) {
+  const float p0 = __fdiv_rn(__fsub_rn(xv, __fmul_rn(c.s1m, e)), c.sqrt_a);
+  float xp = __fadd_rn(__fmul_rn(c.sqrt_aprev, p0), __fmul_rn(c.dir_coef, e));
+  if (noise) xp = __fadd_rn(xp, __fmul_rn(c.sigma, noise[i]));
+  if (orig) {
+    const float ot = __fadd_rn(__fmul_rn(c.q_sqrt_a, orig[i]), __fmul_rn(c.q_s1m, on[i]));
+    const float m = mask[i];
+    xp = __fadd_rn(__fmul_rn(ot, m), __fmul_rn(xp, 1.0f - m));
+  }
+  return xp;
+}
 __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
                                  const float* __restrict__ orig, const float* __restrict__ on, const float* __restrict__ mask,
                                  pf_ddim_coef c, float* __restrict__ out, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float e = eps[i];
-    const float p0 = __fdiv_rn(__fsub_rn(x[i], __fmul_rn(c.s1m, e)), c.sqrt_a);
-    float xp = __fadd_rn(__fmul_rn(c.sqrt_aprev, p0), __fmul_rn(c.dir_coef, e));
-    if (noise) xp = __fadd_rn(xp, __fmul_rn(c.sigma, noise[i]));
-    if (orig) {
-      const float ot = __fadd_rn(__fmul_rn(c.q_sqrt_a, orig[i]), __fmul_rn(c.q_s1m, on[i]));
-      const float m = mask[i];
-      xp = __fadd_rn(__fmul_rn(ot, m), __fmul_rn(xp, 1.0f - m));
-    }
-    out[i] = xp;
-  }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = ddim_update(x[i], eps[i], noise, orig, on, mask, c, i);
+}
+__global__ void ddim_step_dev_kernel(const float* x, const float* __restrict__ eps, const float* __restrict__ noise,
+                                     const float* __restrict__ orig, const float* __restrict__ on, const float* __restrict__ mask,
+                                     const pf_ddim_coef* __restrict__ table, const pf_step_state* __restrict__ st, float* out, size_t n) {
+  const pf_ddim_coef c = table[st->index];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = ddim_update(x[i], eps[i], noise, orig, on, mask, c, i);
+}
+int launch_ddim_step_dev(const float* x, const float* eps, const float* noise, const float* orig, const float* orig_noise,
+                         const float* mask, const pf_ddim_coef* table, const pf_step_state* st, float* out, size_t n, hipStream_t s) {
+  PF_REQUIRE(x && eps && out && table && st && n > 0 && (!orig || (mask && orig_noise)), "ddim_step_dev: bad arguments");
+  hipLaunchKernelGGL(ddim_step_dev_kernel, ew_grid(n), dim3(256), 0, s, x, eps, noise, orig, orig_noise, mask, table, st, out, n);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+// ---- device-resident step state: what changes from one reverse step to the next lives in device memory, so a captured
+// step (hipGraph) can be replayed unchanged
+__global__ void step_state_set_kernel(pf_step_state* st, long long index, unsigned long long draws) { st->index = index; st->draws = draws; }
+__global__ void step_begin_kernel(const pf_step_state* __restrict__ st, const int* __restrict__ time_steps, long long* __restrict__ t_out, int batch) {
+  const long long t = time_steps ? (long long)time_steps[st->index] : (long long)st->index;
+  for (int i = threadIdx.x; i < batch; i += blockDim.x) t_out[i] = t;
+}
+__global__ void step_end_kernel(pf_step_state* st, int draws_used) { st->index -= 1; st->draws += (unsigned long long)draws_used; }
+int launch_step_state_set(pf_step_state* st, int64_t index, uint64_t draws, hipStream_t s) {
+  PF_REQUIRE(st, "step_state_set: null state");
+  hipLaunchKernelGGL(step_state_set_kernel, dim3(1), dim3(1), 0, s, st, (long long)index, (unsigned long long)draws);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+int launch_step_begin(const pf_step_state* st, const int* time_steps, int64_t* t_out, int batch, hipStream_t s) {
+  PF_REQUIRE(st && t_out && batch > 0, "step_begin: bad arguments");
+  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, s, st, time_steps, reinterpret_cast<long long*>(t_out), batch);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+int launch_step_end(pf_step_state* st, int draws_used, hipStream_t s) {
+  PF_REQUIRE(st && draws_used >= 0, "step_end: bad arguments");
+  hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(1), 0, s, st, draws_used);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
 }
 int launch_ddim_step(const float* x, const float* eps, const float* noise, const float* orig, const float* orig_noise,
                      const float* mask, const pf_ddim_coef& c, float* out, size_t n, hipStream_t s) {
@@ -429,7 +488,7 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
   const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
   c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
-__global__ void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed, uint64_t sid, uint64_t off) {
+__device__ __forceinline__ void randn_body(float* __restrict__ out, size_t n, uint64_t seed, uint64_t sid, uint64_t off) {
   const uint64_t g0 = off >> 2, g1 = (off + n + 3) >> 2;
   for (uint64_t g = g0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += (uint64_t)gridDim.x * blockDim.x) {
     uint32_t c0 = (uint32_t)g, c1 = (uint32_t)(g >> 32), c2 = (uint32_t)sid, c3 = (uint32_t)(sid >> 32);
@@ -449,6 +508,17 @@ __global__ void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed, u
       if (e >= off && e < off + n) out[e - off] = z[j];
     }
   }
+}
+__global__ void randn_kernel(float* __restrict__ out, size_t n, uint64_t seed, uint64_t sid, uint64_t off) { randn_body(out, n, seed, sid, off); }
+// draw index = device-resident counter + slot (the position of this draw inside the step)
+__global__ void randn_dev_kernel(float* __restrict__ out, size_t n, uint64_t seed, const pf_step_state* __restrict__ st, int slot, uint64_t off) {
+  randn_body(out, n, seed, st->draws + (uint64_t)slot, off);
+}
+int launch_randn_dev(float* out, size_t n, uint64_t seed, const pf_step_state* st, int slot, uint64_t elem_offset, hipStream_t s) {
+  PF_REQUIRE(out && st && n > 0 && slot >= 0, "randn_dev: bad arguments");
+  hipLaunchKernelGGL(randn_dev_kernel, ew_grid(n / 4 + 1), dim3(256), 0, s, out, n, seed, st, slot, elem_offset);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
 }
 int launch_randn(float* out, size_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, hipStream_t s) {
   PF_REQUIRE(out && n > 0, "randn: bad arguments");

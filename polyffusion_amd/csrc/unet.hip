@@ -926,5 +926,21 @@ int pf_ddim_step(const float* x, const float* eps, const float* noise, const flo
 int pf_randn(float* out, size_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, void* stream) {
   return launch_randn(out, n, seed, stream_id, elem_offset, (hipStream_t)stream);
 }
+int pf_step_state_set(pf_step_state* st, int64_t index, uint64_t draws, void* stream) { return launch_step_state_set(st, index, draws, (hipStream_t)stream); }
+int pf_step_begin(const pf_step_state* st, const int32_t* time_steps, int64_t* t_out, int batch, void* stream) {
+  return launch_step_begin(st, time_steps, t_out, batch, (hipStream_t)stream);
+}
+int pf_step_end(pf_step_state* st, int draws_used, void* stream) { return launch_step_end(st, draws_used, (hipStream_t)stream); }
+int pf_randn_dev(float* out, size_t n, uint64_t seed, const pf_step_state* st, int slot, uint64_t elem_offset, void* stream) {
+  return launch_randn_dev(out, n, seed, st, slot, elem_offset, (hipStream_t)stream);
+}
+int pf_ddpm_step_dev(const float* x, const float* eps, const float* noise_p, const float* noise_q, const float* orig, const float* mask,
+                     const pf_ddpm_coef* table, const pf_step_state* st, float* x_out, size_t n, void* stream) {
+  return launch_ddpm_step_dev(x, eps, noise_p, noise_q, orig, mask, table, st, x_out, n, (hipStream_t)stream);
+}
+int pf_ddim_step_dev(const float* x, const float* eps, const float* noise, const float* orig, const float* orig_noise, const float* mask,
+                     const pf_ddim_coef* table, const pf_step_state* st, float* x_out, size_t n, void* stream) {
+  return launch_ddim_step_dev(x, eps, noise, orig, orig_noise, mask, table, st, x_out, n, (hipStream_t)stream);
+}
 
 }  // extern "C"

@@ -38,8 +38,42 @@ def init_from_env():
     return rank, world, local
 
 
+_direct_comm = None
+
+
+def _direct(rank: int, world: int):
+    """pf_comm over librccl directly (include/pfhip.h): the 128-byte unique id travels through a TCPStore next to
+    the torchrun rendezvous port; no torch.distributed process group is involved."""
+    global _direct_comm
+    if _direct_comm is None:
+        import ctypes as C
+        from datetime import timedelta
+        from . import _lib
+        lib = _lib.load()
+        host, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 1
+        store = dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=timedelta(seconds=120))
+        uid = (C.c_char * 128)()
+        if rank == 0:
+            _lib.check(lib.pf_comm_unique_id(uid), "pf_comm_unique_id")
+            store.set("pf_comm_uid", bytes(uid.raw))
+        else:
+            uid.raw = store.get("pf_comm_uid")
+        h = C.c_void_p()
+        _lib.check(lib.pf_comm_init(uid, rank, world, C.byref(h)), "pf_comm_init")
+        _direct_comm = (lib, h, store)
+    return _direct_comm
+
+
 def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
-    """In-place broadcast of a packed weight blob (a no-op in single-process runs)."""
+    """In-place broadcast of a packed weight blob (a no-op in single-process runs).  Default transport: torch.distributed
+    (backend nccl = RCCL over xGMI; gloo in the CPU tests).  PF_COMM_DIRECT=1 uses the library's own pf_comm_bcast (librccl
+    opened by libpfhip.so itself) - same wire protocol, no process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("PF_COMM_DIRECT") == "1" and blob.is_cuda:
+        from . import _lib
+        lib, h, _ = _direct(int(os.environ.get("RANK", "0")), world)
+        _lib.check(lib.pf_comm_bcast(h, blob.data_ptr(), blob.numel() * blob.element_size(), src, _lib.current_stream()), "pf_comm_bcast")
+        return blob
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast(blob, src=src)
     return blob

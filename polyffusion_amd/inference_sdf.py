@@ -307,6 +307,8 @@ def make_parser() -> ArgumentParser:
                    "db_pos_filter, chord - what get_data_for_single_midi / the POP909 .npz files hold): its 8-bar segments supply the "
                    "chord / texture conditions and the image to inpaint (ref:inference_sdf.py:599-610 via data/datasample.py)")
     p.add_argument("--bar_list", help="bars to inpaint for --inpaint_type bars, comma separated")
+    p.add_argument("--hip_graph", action="store_true", help="capture one reverse step as a hipGraph and replay it (same results; "
+                   "removes the host-side launch cost that bounds small batches, e.g. the batch-1 runs of --autoreg)")
     return p
 
 
@@ -357,12 +359,13 @@ def load_model(params, args, rank: int = 0, world: int = 1) -> Polyffusion_SDF:
 def make_sampler(model, args, seed: int, sample_offset: int = 0):
     """(sampler, start index) as ``inference_sdf.py:735-747,215-219`` choose them."""
     if args.ddim:
-        sampler = DDIMSampler(model.ldm, args.ddim_steps, args.ddim_discretize, args.ddim_eta, seed=seed, sample_offset=sample_offset)
+        sampler = DDIMSampler(model.ldm, args.ddim_steps, args.ddim_discretize, args.ddim_eta, seed=seed, sample_offset=sample_offset,
+                              graph=getattr(args, "hip_graph", False))
         t_idx = args.ddim_steps - 1    # inference_sdf.py:218 (NOT len(time_steps)-1: 'uniform' can yield one more entry)
         if t_idx >= len(sampler.time_steps):
             raise SystemExit(f"--ddim_steps {args.ddim_steps}: the discretisation has only {len(sampler.time_steps)} steps")
         return sampler, t_idx
-    return SDFSampler(model.ldm, seed=seed, sample_offset=sample_offset), None
+    return SDFSampler(model.ldm, seed=seed, sample_offset=sample_offset, graph=getattr(args, "hip_graph", False)), None
 
 
 def generate_songs(model, params, args, cond, cond_mid, orig, mask, seed: int, rank: int = 0, world: int = 1):

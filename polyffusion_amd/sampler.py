@@ -33,7 +33,8 @@ NoiseFn = Callable[[tuple], torch.Tensor]
 class DiffusionSampler:
     model: LatentDiffusion
 
-    def __init__(self, model: LatentDiffusion, noise_fn: Optional[NoiseFn] = None, seed: int = 0, sample_offset: int = 0):
+    def __init__(self, model: LatentDiffusion, noise_fn: Optional[NoiseFn] = None, seed: int = 0, sample_offset: int = 0,
+                 graph: bool = False):
         self.model = model
         self.n_steps = model.n_steps
         self.noise_fn = noise_fn
@@ -42,6 +43,37 @@ class DiffusionSampler:
         self._draws = 0
         self._lib = _lib.load()
         self._tbuf = None
+        # graph=True: paint() captures ONE reverse step as a hipGraph and replays it.  What varies per step
+        # (table row, time-step value, noise draw counter) lives in a device-resident pf_step_state, the coefficient table is on
+        # the device, x is updated in place: a replay issues no host-side launches (about 220 per step in eager mode), which is
+        # what bounds small batches (batch 1 of the --autoreg CLI, batch 8 per GPU of BASELINE config 5).  Results are bit-identical
+        # to the eager loop.  Used only with the on-device noise generator (an injected noise_fn is host code).
+        self.graph = bool(graph)
+        self._dev_cache = {}
+
+    def _step_state(self, device) -> torch.Tensor:
+        key = ("state", str(device))
+        if key not in self._dev_cache:
+            self._dev_cache[key] = torch.zeros(2, dtype=torch.int64, device=device)   # pf_step_state {int64 index; uint64 draws}
+        return self._dev_cache[key]
+
+    def _set_state(self, st: torch.Tensor, index: int):
+        _lib.check(self._lib.pf_step_state_set(st.data_ptr(), int(index), int(self._draws), _lib.current_stream()), "pf_step_state_set")
+
+    def _capture(self, body, restore):
+        """Warm `body` up once on a side stream (sizes the workspace, primes the allocator), undo its effect with `restore`,
+        then capture it.  Returns the instantiated graph."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            body()
+            restore()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            body()
+        restore()
+        return g
 
     # ---- noise ------------------------------------------------------------------------------------
     def randn(self, shape, device) -> torch.Tensor:
@@ -93,6 +125,53 @@ class SDFSampler(DiffusionSampler):
         self.mean_x0_coef = beta * (ab_prev ** 0.5) / (1.0 - ab)
         self.mean_xt_coef = (1.0 - ab_prev) * ((1 - beta) ** 0.5) / (1.0 - ab)
         self._sigma = (0.5 * self.log_var).exp()
+
+    def _coef_table(self, device) -> torch.Tensor:
+        """[n_steps, 7] fp32 on the device: row t = the pf_ddpm_coef of step t (same floats `_coef` passes by value)."""
+        key = ("ddpm_table", str(device))
+        if key not in self._dev_cache:
+            rows = torch.stack([self.sqrt_recip_alpha_bar, self.sqrt_recip_m1_alpha_bar, self.mean_x0_coef, self.mean_xt_coef,
+                                self._sigma, self.sqrt_alpha_bar, self.sqrt_1m_alpha_bar], dim=1).to(torch.float32).contiguous()
+            self._dev_cache[key] = rows.to(device)
+        return self._dev_cache[key]
+
+    def _paint_graph(self, x, cond, t_start, orig, mask, uncond_scale, uncond_cond, cond_concat):
+        """Steps t_start .. 1 as replays of one captured step; returns x_1 (the caller runs step 0, which draws no noise)."""
+        lib, dev, B, n = self._lib, x.device, x.shape[0], x.numel()
+        table, st = self._coef_table(dev), self._step_state(dev)
+        xb = x.clone()
+        tb = torch.empty(B, dtype=torch.long, device=dev)
+        nq = torch.empty_like(xb) if orig is not None else None
+        npz = torch.empty_like(xb)
+        off = self.sample_offset * (n // B)
+        ndraw = 2 if orig is not None else 1
+
+        def body():
+            stream = _lib.current_stream()
+            _lib.check(lib.pf_step_begin(st.data_ptr(), None, tb.data_ptr(), B, stream), "pf_step_begin")
+            if orig is not None:   # draw order of the reference: known-region noise first, then the p_sample noise
+                _lib.check(lib.pf_randn_dev(nq.data_ptr(), n, self.seed, st.data_ptr(), 0, off, stream), "pf_randn_dev")
+            xin = xb if cond_concat is None else torch.cat([xb, cond_concat], dim=1)
+            e_t = self.get_eps(xin, tb, cond, uncond_scale=uncond_scale, uncond_cond=uncond_cond)
+            _lib.check(lib.pf_randn_dev(npz.data_ptr(), n, self.seed, st.data_ptr(), ndraw - 1, off, stream), "pf_randn_dev")
+            _lib.check(lib.pf_ddpm_step_dev(xb.data_ptr(), e_t.data_ptr(), npz.data_ptr(), _lib.ptr(nq), _lib.ptr(orig), _lib.ptr(mask),
+                                            table.data_ptr(), st.data_ptr(), xb.data_ptr(), n, stream), "pf_ddpm_step_dev")
+            _lib.check(lib.pf_step_end(st.data_ptr(), ndraw, stream), "pf_step_end")
+
+        def restore():
+            xb.copy_(x)
+            self._set_state(st, t_start)
+
+        self._set_state(st, t_start)
+        g = self._capture(body, restore)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(t_start):
+            g.replay()
+        e1.record()
+        self.last_replay = (e0, e1, t_start)     # bench.py reads the per-step replay time from these events
+        self._draws += ndraw * t_start
+        return xb
 
     def _coef(self, step: int) -> _lib.DdpmCoef:
         return _lib.DdpmCoef(float(self.sqrt_recip_alpha_bar[step]), float(self.sqrt_recip_m1_alpha_bar[step]),
@@ -149,7 +228,11 @@ class SDFSampler(DiffusionSampler):
             assert mask is not None
             orig, mask = orig.contiguous().float(), mask.contiguous().float()
         n = x.numel()
-        for step in np.flip(self.time_steps[: t_start + 1]):
+        steps = np.flip(self.time_steps[: t_start + 1])
+        if self.graph and self.noise_fn is None and repaint_n == 1 and t_start >= 1:
+            x = self._paint_graph(x, cond, int(t_start), orig, mask, uncond_scale, uncond_cond, cond_concat)
+            steps = steps[-1:]          # step 0 (no noise) runs eagerly below
+        for step in steps:
             step = int(step)
             coef = self._coef(step)
             if orig is None:
@@ -195,6 +278,45 @@ class DDIMSampler(DiffusionSampler):
         self.ddim_sigma = (ddim_eta * ((1 - self.ddim_alpha_prev) / (1 - self.ddim_alpha)
                                        * (1 - self.ddim_alpha / self.ddim_alpha_prev)) ** 0.5)
         self.ddim_sqrt_one_minus_alpha = (1.0 - self.ddim_alpha) ** 0.5
+
+    def _coef_table(self, device):
+        """([S, 7] fp32 coefficient rows, [S] int32 tau table) on the device - the floats `_coef` passes by value."""
+        key = ("ddim_table", str(device))
+        if key not in self._dev_cache:
+            rows = torch.tensor([[getattr(c, f) for f, _ in _lib.DdimCoef._fields_] for c in map(self._coef, range(len(self.time_steps)))],
+                                dtype=torch.float32)
+            self._dev_cache[key] = (rows.to(device), torch.from_numpy(np.asarray(self.time_steps, dtype=np.int32)).to(device))
+        return self._dev_cache[key]
+
+    def _paint_graph(self, x, cond, t_start, orig, mask, orig_noise, uncond_scale, uncond_cond, cond_concat):
+        """All t_start+1 steps of a deterministic (eta = 0) DDIM loop as replays of one captured step."""
+        lib, dev, B, n = self._lib, x.device, x.shape[0], x.numel()
+        (table, taus), st = self._coef_table(dev), self._step_state(dev)
+        xb = x.clone()
+        tb = torch.empty(B, dtype=torch.long, device=dev)
+
+        def body():
+            stream = _lib.current_stream()
+            _lib.check(lib.pf_step_begin(st.data_ptr(), taus.data_ptr(), tb.data_ptr(), B, stream), "pf_step_begin")
+            xin = xb if cond_concat is None else torch.cat([xb, cond_concat], dim=1)
+            e_t = self.get_eps(xin, tb, cond, uncond_scale=uncond_scale, uncond_cond=uncond_cond)
+            _lib.check(lib.pf_ddim_step_dev(xb.data_ptr(), e_t.data_ptr(), None, _lib.ptr(orig), _lib.ptr(orig_noise), _lib.ptr(mask),
+                                            table.data_ptr(), st.data_ptr(), xb.data_ptr(), n, stream), "pf_ddim_step_dev")
+            _lib.check(lib.pf_step_end(st.data_ptr(), 0, stream), "pf_step_end")
+
+        def restore():
+            xb.copy_(x)
+            self._set_state(st, t_start)
+
+        self._set_state(st, t_start)
+        g = self._capture(body, restore)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(t_start + 1):
+            g.replay()
+        e1.record()
+        self.last_replay = (e0, e1, t_start + 1)
+        return xb
 
     def _coef(self, index: int) -> _lib.DdimCoef:
         a, ap, sg = self.ddim_alpha[index], self.ddim_alpha_prev[index], self.ddim_sigma[index]
@@ -263,6 +385,9 @@ class DDIMSampler(DiffusionSampler):
             orig, mask = orig.contiguous().float(), mask.contiguous().float()
             orig_noise = None if orig_noise is None else orig_noise.contiguous().float()
         time_steps = np.flip(self.time_steps[: t_start + 1])
+        if (self.graph and self.noise_fn is None and not bool((self.ddim_sigma[: t_start + 1] != 0).any())
+                and (orig is None or orig_noise is not None)):
+            return self._paint_graph(x, cond, int(t_start), orig, mask, orig_noise, uncond_scale, uncond_cond, cond_concat)
         for i, step in enumerate(time_steps):
             index = len(time_steps) - i - 1
             e_t = self._eps(x, cond, int(step), uncond_scale, uncond_cond, cond_concat)

@@ -111,3 +111,69 @@ def test_on_device_noise_is_shard_invariant(ldm):
     whole2 = torch.cat([run(0, 2), run(2, 4)])
     assert torch.equal(halves, whole2)
     assert (halves - full).abs().max() < 1e-4
+
+
+def test_graph_replay_is_bit_identical_to_the_eager_loop(ldm):
+    """hipGraph mode: one captured step replayed with device-resident step state (table row, time step, draw counter) must give
+    exactly what the eager loop gives - 10 DDPM steps with inpainting + CFG, a generate-path run without orig, and DDIM eta 0."""
+    rng = np.random.Generator(np.random.PCG64(31))
+    B = 3
+    cond = torch.from_numpy(rng.standard_normal((B, 1, 32)).astype(np.float32)).cuda()
+    uc = -torch.ones(B, 1, 32).cuda()
+    orig = torch.from_numpy((rng.random((B, 2, 16, 16)) < 0.1).astype(np.float32)).cuda()
+    mask = torch.zeros(B, 2, 16, 16).cuda()
+    mask[:, :, :6] = 1
+
+    def ddpm(graph, with_orig, scale):
+        s = SDFSampler(ldm, seed=42, sample_offset=5, graph=graph)
+        x = s.randn((B, 2, 16, 16), cond.device)
+        out = s.paint(x, cond, 9, orig=orig if with_orig else None, mask=mask if with_orig else None, uncond_scale=scale, uncond_cond=uc)
+        return out, s._draws
+
+    for with_orig, scale in ((True, 2.0), (False, 1.0), (True, 0.0)):
+        (a, da), (b, db) = ddpm(False, with_orig, scale), ddpm(True, with_orig, scale)
+        assert da == db                      # the host-side draw counter advanced identically
+        assert torch.equal(a, b), (with_orig, scale, (a - b).abs().max().item())
+        assert torch.isfinite(a).all() and a.std() > 0
+
+    def ddim(graph):
+        d = DDIMSampler(ldm, 10, "uniform", 0.0, seed=42, graph=graph)
+        x = d.randn((B, 2, 16, 16), cond.device)
+        return d.paint(d.q_sample(orig, 6, x), cond, 6, orig=orig, mask=mask, orig_noise=x, uncond_scale=3.0, uncond_cond=uc)
+
+    assert torch.equal(ddim(False), ddim(True))
+    # a second paint() on the same sampler object continues the draw sequence in both modes
+    s1, s2 = SDFSampler(ldm, seed=1, graph=False), SDFSampler(ldm, seed=1, graph=True)
+    for s in (s1, s2):
+        s.out = [s.paint(s.randn((B, 2, 16, 16), cond.device), cond, 3, orig=orig, mask=mask) for _ in range(2)]
+    assert torch.equal(s1.out[0], s2.out[0]) and torch.equal(s1.out[1], s2.out[1]) and not torch.equal(s1.out[0], s1.out[1])
+
+
+def test_comm_single_rank_broadcast():
+    """pf_comm_* (RCCL reached directly through dlopen): a 1-rank communicator initialises from its own unique id and
+    a broadcast from root 0 leaves the buffer unchanged.  (Multi-rank use: polyffusion_amd.dist.broadcast_blob with PF_COMM_DIRECT=1.)"""
+    import ctypes as C
+    lib = _lib.load()
+    uid = (C.c_char * 128)()
+    _lib.check(lib.pf_comm_unique_id(uid), "pf_comm_unique_id")
+    comm = C.c_void_p()
+    _lib.check(lib.pf_comm_init(uid, 0, 1, C.byref(comm)), "pf_comm_init")
+    buf = torch.arange(4096, dtype=torch.float32, device="cuda")
+    _lib.check(lib.pf_comm_bcast(comm, buf.data_ptr(), buf.numel() * 4, 0, _lib.current_stream()), "pf_comm_bcast")
+    torch.cuda.synchronize()
+    assert torch.equal(buf.cpu(), torch.arange(4096, dtype=torch.float32))
+    _lib.check(lib.pf_comm_destroy(comm), "pf_comm_destroy")
+
+
+def test_direct_broadcast_path_single_rank(monkeypatch):
+    """dist.broadcast_blob(PF_COMM_DIRECT=1): TCPStore id exchange + pf_comm_init + pf_comm_bcast, executed with world size 1."""
+    from polyffusion_amd import dist as pfdist
+    monkeypatch.setenv("PF_COMM_DIRECT", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29731")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    blob = torch.arange(1000, dtype=torch.float32, device="cuda")
+    out = pfdist.broadcast_blob(blob, 0)
+    torch.cuda.synchronize()
+    assert out is blob and float(blob.sum()) == 499500.0
