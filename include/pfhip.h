@@ -219,6 +219,14 @@ typedef struct pf_conv_args {
   const float* skip_x1; int32_t skip_c1;
   const void* skip_w;
   const float* skip_bias;
+  /* optional (bf16x3, prologue 1 or 2): GroupNorm scale/shift computed INSIDE the launch from the producers' per-tile statistics
+   * (what pf_gn_finalize_tiles computes in its own launch): every workgroup reduces its sample's statistics at start-up and writes
+   * the sample's rows of `sc` / `sh` (identical values from every workgroup of the sample) before it reads them.  gn_stats0 != NULL
+   * enables it; tensors with many tiles per sample (the 128x128 / 64x64 levels) are better served by the separate launch. */
+  const float* gn_stats0; int32_t gn_tiles0;
+  const float* gn_stats1; int32_t gn_tiles1;
+  const float* gn_gamma; const float* gn_beta;
+  float gn_eps; int32_t gn_groups;
 } pf_conv_args;
 /* scratch bytes a launch with these arguments would like for split-K (0 = the launch does not split) */
 size_t pf_conv_splitk_ws_bytes(const pf_conv_args* a);

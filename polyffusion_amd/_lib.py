@@ -53,6 +53,8 @@ class ConvArgs(C.Structure):
         ("ups_fold", C.c_int32),
         ("skip_x0", C.c_void_p), ("skip_c0", C.c_int32), ("skip_x1", C.c_void_p), ("skip_c1", C.c_int32),
         ("skip_w", C.c_void_p), ("skip_bias", C.c_void_p),
+        ("gn_stats0", C.c_void_p), ("gn_tiles0", C.c_int32), ("gn_stats1", C.c_void_p), ("gn_tiles1", C.c_int32),
+        ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float), ("gn_groups", C.c_int32),
     ]
 
 

@@ -259,9 +259,23 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       for (int r = 0; r < 16; ++r) acc[fm][fn][r] = 0.f;
 
 
+  // GroupNorm finalize folded into this launch (pf_conv_args.gn_*): runs while the first tile's loads are in flight - the halo /
+  // A-tile region of the LDS serves as its scratch and is only written by storeA afterwards - then re-reads chunk 0's scale/shift
+  // (loadA fetched them before they existed).
+  auto gnFused = [&]() {
+    if constexpr (PRO == 1 || PRO == 2) {
+      if (p.gn_s0) {
+        gn_fused_prologue<KG * NT>(p, b, threadIdx.x, p.Hin * p.Win, reinterpret_cast<double*>(smem_all));
+        const int cg = cbeg * BK;
+        vsc = *reinterpret_cast<const f32x4*>(p.sc + (size_t)b * cin + cg + c4 * 4);
+        vsh = *reinterpret_cast<const f32x4*>(p.sh + (size_t)b * cin + cg + c4 * 4);
+      }
+    }
+  };
   if constexpr (KS == 1) {
     // 1x1 / linear: A and W tiles both change every chunk; register-staged, double-buffered, one barrier per chunk
     loadA(0); loadW(0, 0);
+    gnFused();
     storeA(0); storeW(0);
     __syncthreads();
     for (int chunk = 0; chunk < nchunk; ++chunk) {
@@ -322,6 +336,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     TR();
     loadA(0);
     TR();
+    gnFused();
     storeA(0);
     TR();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -769,6 +784,10 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   p.ksplit = conv_ksplit(a);
   p.partial = p.ksplit > 1 ? static_cast<float*>(a.splitk_ws) : nullptr;
   p.qkv = a.qkv_planes; p.out_planes = a.out_planes;
+  if (a.gn_stats0 && (a.prologue == 1 || a.prologue == 2)) {
+    p.gn_s0 = a.gn_stats0; p.gn_t0 = a.gn_tiles0; p.gn_s1 = a.gn_stats1; p.gn_t1 = a.gn_tiles1;
+    p.gn_gamma = a.gn_gamma; p.gn_beta = a.gn_beta; p.gn_eps = a.gn_eps; p.gn_groups = a.gn_groups;
+  }
   p.sx0 = a.skip_x0; p.sc0 = a.skip_c0; p.sx1 = a.skip_x1; p.sc1 = a.skip_c1; p.sw = a.skip_w; p.bias2 = a.skip_w ? a.skip_bias : nullptr;
   const int tile = conv_pick_tile(a);
   if (a.ks == 1) {

@@ -47,7 +47,49 @@ struct ConvP {
   void* out_planes;             // result as bf16 hi/lo planes [M][ld_out] | [M][ld_out] instead of fp32 (consumer: gemm_planes_bf3.hip)
   void* qkv;                    // fused q|k|v projection written as bf16 hi/lo planes for attention_bf3.hip (d_head 64)
   int ksplit; float* partial;   // split-K: raw accumulators to partial[split][M][N]; bias/residual/statistics happen in the reduce kernel
+  // GroupNorm finalize inside the consumer (bf16x3 kernels): per-tile statistics of the one or two producers, see gn_fused_prologue
+  const float* gn_s0; const float* gn_s1; int gn_t0, gn_t1;
+  const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_groups;
 };
+
+// GroupNorm scale/shift of THIS workgroup's sample, computed by the consuming kernel itself instead of a separate finalize launch
+// (a 5 us launch between every two convolutions).  Same arithmetic as gn_finalize_tiles_kernel: the per-tile
+// (sum, sumsq) of every channel are added in fp64, then the group's channels, mean / rstd in fp64, scale = gamma*rstd and
+// shift = beta - mean*rstd*gamma rounded to fp32.  Every workgroup of a sample writes the same values to the sample's rows of
+// p.sc / p.sh; the block-level fence + barrier make them visible to this workgroup's own later loads.  Deterministic.
+// `scratch`: LDS, 2*cin doubles, not in use by anything else yet.  Must be called by all NTHREADS threads of the workgroup.
+template <int NTHREADS>
+__device__ __forceinline__ void gn_fused_prologue(const ConvP& p, int b, int tid_wg, int hw, double* scratch) {
+  const int cin = p.c0 + p.c1, gs = cin / p.gn_groups;
+  for (int c = tid_wg; c < cin; c += NTHREADS) {
+    const float* s; int T, C, cl;
+    if (c < p.c0) { s = p.gn_s0; T = p.gn_t0; C = p.c0; cl = c; } else { s = p.gn_s1; T = p.gn_t1; C = p.c1; cl = c - p.c0; }
+    double a = 0.0, q = 0.0;
+    for (int t = 0; t < T; ++t) {
+      const float2 v = *reinterpret_cast<const float2*>(s + (((size_t)b * T + t) * C + cl) * 2);
+      a += v.x; q += v.y;
+    }
+    scratch[2 * c] = a; scratch[2 * c + 1] = q;
+  }
+  __syncthreads();
+  float* scw = const_cast<float*>(p.sc) + (size_t)b * cin;
+  float* shw = const_cast<float*>(p.sh) + (size_t)b * cin;
+  for (int c = tid_wg; c < cin; c += NTHREADS) {
+    const int g0 = (c / gs) * gs;
+    double a = 0.0, q = 0.0;
+    for (int j = 0; j < gs; ++j) { a += scratch[2 * (g0 + j)]; q += scratch[2 * (g0 + j) + 1]; }
+    const double cnt = (double)gs * hw;
+    const double mean = a / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)p.gn_eps);
+    const double ga = p.gn_gamma[c];
+    scw[c] = (float)(rstd * ga);
+    shw[c] = (float)((double)p.gn_beta[c] - mean * rstd * ga);
+  }
+  __threadfence_block();
+  __syncthreads();
+}
 
 // x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division sequence (10 instructions shorter)
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }

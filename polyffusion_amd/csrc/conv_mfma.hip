@@ -332,6 +332,9 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
   PF_REQUIRE(a.n > 0 && a.w && a.out, "conv: null weight/output");
   PF_REQUIRE(a.prologue >= 0 && a.prologue <= 3, "conv: bad prologue %d", a.prologue);
   PF_REQUIRE(a.prologue == 0 || (a.sc && a.sh), "conv: prologue needs sc/sh");
+  PF_REQUIRE(!a.gn_stats0 || (a.precision == PF_PREC_BF16X3 && (a.prologue == 1 || a.prologue == 2) && a.gn_gamma && a.gn_beta && a.gn_groups > 0 &&
+                              (a.c0 + a.c1) % a.gn_groups == 0 && a.c0 + a.c1 <= 1024 && a.gn_tiles0 > 0 && (a.c1 == 0 || (a.gn_stats1 && a.gn_tiles1 > 0))),
+             "conv: fused GroupNorm finalize needs the bf16x3 path, prologue 1/2, gamma/beta, statistics of every source and <= 1024 channels");
   PF_REQUIRE(a.prologue != 3 || (a.mean && a.rstd && a.ks == 1), "conv: LayerNorm prologue needs mean/rstd and ks=1");
   PF_REQUIRE(!a.geglu || (a.n % 64 == 0 && !a.sbias && !a.res), "conv: geglu needs N %% 64 == 0 and no residual");
   PF_REQUIRE((a.ks == 3 && (a.prologue == 0 || a.prologue == 1)) || a.ks == 1, "conv: 3x3 supports prologue 0/1 only");

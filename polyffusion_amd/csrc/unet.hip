@@ -426,8 +426,27 @@ struct Ctx {
     }
     prof_end();
   }
-  // GroupNorm scale/shift of concat(x0, x1) from the producers' tile statistics (no pass over the data)
-  void gn(const Tn& x0, const Tn& x1, int hw, float eps, size_t g, size_t b_, float* sc, float* sh) {
+  // GroupNorm scale/shift of concat(x0, x1) from the producers' tile statistics (no pass over the data).
+  // `fuse_ok`: the consumer is a bf16x3 conv that can do this reduction in its own prologue (pf_conv_args.gn_*): worth it when a
+  // sample has few statistics tiles (the 32x32 / 16x16 levels: <= 16 tiles), where the 5 us finalize launch is 10-20 % of the
+  // convolution it feeds; at the 128x128 / 64x64 levels every consumer workgroup would re-read 32-64 KB, so the launch stays.
+  struct GnRef { bool fused = false; const float* s0 = nullptr; const float* s1 = nullptr; int t0 = 0, t1 = 0; size_t g = 0, b = 0; float eps = 0.f; };
+  GnRef gn(const Tn& x0, const Tn& x1, int hw, float eps, size_t g, size_t b_, float* sc, float* sh, bool fuse_ok = false) {
+    static const bool no_fuse = getenv("PF_NO_GN_FUSE") != nullptr;   // experiment hook
+    const int cin_ = x0.c + x1.c;
+    if (fuse_ok && !no_fuse && u->precision == PF_PREC_BF16X3 && cin_ % 32 == 0 && cin_ <= 1024 && x0.nt <= 16 && (x1.c == 0 || x1.nt <= 16)) {
+      GnRef r; r.fused = true; r.s0 = x0.st; r.t0 = x0.nt; r.s1 = x1.st; r.t1 = x1.nt; r.g = g; r.b = b_; r.eps = eps;
+      return r;
+    }
+    gn_launch(x0, x1, hw, eps, g, b_, sc, sh);
+    return GnRef{};
+  }
+  void gn_attach(pf_conv_args& a, const GnRef& r) {
+    if (!r.fused) return;
+    a.gn_stats0 = dry ? (const float*)16 : r.s0; a.gn_tiles0 = r.t0; a.gn_stats1 = r.s1; a.gn_tiles1 = r.t1;
+    a.gn_gamma = w(r.g); a.gn_beta = w(r.b); a.gn_eps = r.eps; a.gn_groups = 32;
+  }
+  void gn_launch(const Tn& x0, const Tn& x1, int hw, float eps, size_t g, size_t b_, float* sc, float* sh) {
     prof_begin(PF_K_GNSTAT, 0.0);
     if (!dry && rc == PF_OK)
       rc = launch_gn_finalize_tiles(x0.st, x0.nt, x0.c, x1.st, x1.nt, x1.c, B, hw, 32, eps, w(g), w(b_), sc, sh, s);
@@ -470,15 +489,16 @@ static Tn run_res(Ctx& c, const Layer& L, const Tn& x0, const Tn& x1, int H, int
   float* sc1 = c.talloc((size_t)B * ci); float* sh1 = c.talloc((size_t)B * ci);
   float* h = c.talloc((size_t)B * hw * co);
   float* sc2 = c.talloc((size_t)B * co); float* sh2 = c.talloc((size_t)B * co);
-  c.gn(x0, x1, hw, 1e-5f, L.gn1_g, L.gn1_b, sc1, sh1);
+  const Ctx::GnRef g1 = c.gn(x0, x1, hw, 1e-5f, L.gn1_g, L.gn1_b, sc1, sh1, true);
   Tn ht;
   {
     pf_conv_args a = conv_base(x0.d, x0.c, x1.d, x1.c, B, H, W_, 3, c.w(L.w1), co, h);
     a.prologue = 1; a.sc = sc1; a.sh = sh1; a.bias = c.w(L.b1);
+    c.gn_attach(a, g1);
     a.sbias = c.dry ? nullptr : tb_all + L.emb_off; a.ld_sbias = c.u->sum_emb;
     c.conv(a, PF_K_CONV3, &ht, false);
   }
-  c.gn(ht, Tn{}, hw, 1e-5f, L.gn2_g, L.gn2_b, sc2, sh2);
+  const Ctx::GnRef g2 = c.gn(ht, Tn{}, hw, 1e-5f, L.gn2_g, L.gn2_b, sc2, sh2, true);
   const float* res = x0.d;
   // bf16x3: the 1x1 skip_connection conv is folded into the second 3x3 conv as one more K range (no round trip of the
   // projected tensor through HBM, one launch less)
@@ -494,6 +514,7 @@ static Tn run_res(Ctx& c, const Layer& L, const Tn& x0, const Tn& x1, int H, int
   {
     pf_conv_args a = conv_base(h, co, nullptr, 0, B, H, W_, 3, c.w(L.w2), co, out);
     a.prologue = 1; a.sc = sc2; a.sh = sh2; a.bias = c.w(L.b2);
+    c.gn_attach(a, g2);
     if (fuse_skip) {
       a.skip_x0 = x0.d; a.skip_c0 = x0.c; a.skip_x1 = x1.d; a.skip_c1 = x1.c;
       a.skip_w = c.dry ? (const void*)1 : (const void*)(c.w(L.wskip) + (size_t)ci * ((co + 63) / 64 * 64));   // its bf16x3 packing
@@ -519,10 +540,11 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
   float* ff = c.talloc((size_t)M * 4 * C);
   float* kv = nullptr;
   if (c.n_cond > 1) kv = c.talloc((size_t)B * c.n_cond * 2 * C);
-  c.gn(xin, Tn{}, hw, 1e-6f, L.norm_g, L.norm_b, sc, sh);
+  const Ctx::GnRef gin = c.gn(xin, Tn{}, hw, 1e-6f, L.norm_g, L.norm_b, sc, sh, true);
   {
     pf_conv_args a = conv_base(x, C, nullptr, 0, B, 1, hw, 1, c.w(L.pin_w), C, ta);
     a.prologue = 2; a.sc = sc; a.sh = sh; a.bias = c.w(L.pin_b);
+    c.gn_attach(a, gin);
     c.conv(a, PF_K_GEMM);
   }
   float* t0 = ta; float* t1 = tbuf; float* t2 = tc;

@@ -399,3 +399,46 @@ def test_full_unet_txt_bf16x3_vs_reference_golden(golden):
     c = torch.from_numpy(synth.gaussian((1, 1, 1024), int(g["cond_seed"]))).cuda()
     o = m(x, torch.from_numpy(g["t"]).cuda(), c).cpu().numpy()
     assert np.abs(o - g["out"]).max() < 5e-4
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,cout,tiles", [(2, 16, 16, 256, 0, 256, 4), (3, 32, 32, 256, 128, 128, 8), (1, 16, 16, 64, 32, 64, 3)])
+def test_groupnorm_finalize_inside_the_consumer(lib, B, H, W, c0, c1, cout, tiles):
+    """pf_conv_args.gn_*: the consuming conv reduces the producers' per-tile (sum, sumsq) itself (no pf_gn_finalize_tiles launch).
+    The tile statistics are built here from the data (any split of the pixels into `tiles` parts is a valid producer layout); the
+    result must equal the two-launch path, and the scale/shift rows the kernel wrote must equal the separate finalize's."""
+    cin = c0 + c1
+    x = rnd((B, cin, H, W), 51) * 1.3 + 0.2
+    w, bias = rnd((cout, cin, 3, 3), 52, (1.0 / (cin * 9)) ** 0.5), rnd((cout,), 53, 0.1)
+    gamma, beta = 1 + 0.1 * rnd((cin,), 54), 0.1 * rnd((cin,), 55)
+    ref = F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-5)), w, bias, padding=1)
+    xh = nhwc(x).reshape(B, H * W, cin)
+
+    def tile_stats(part, nt):     # [B, nt, C, 2] fp32: per-part channel sums, as a producing conv's epilogue would emit them
+        chunks = part.double().tensor_split(nt, dim=1)
+        return torch.stack([torch.stack([c.sum(1), (c * c).sum(1)], dim=-1) for c in chunks], dim=1).float().cuda().contiguous()
+
+    s0 = tile_stats(xh[..., :c0], tiles)
+    s1 = tile_stats(xh[..., c0:], tiles + 1) if c1 else None
+    x0 = dev(nhwc(x[:, :c0]))
+    x1 = dev(nhwc(x[:, c0:])) if c1 else None
+    g, bt = dev(gamma), dev(beta)
+    # reference path: separate finalize launch
+    sc_ref, sh_ref = torch.empty(B, cin, device="cuda"), torch.empty(B, cin, device="cuda")
+    _lib.check(lib.pf_gn_finalize_tiles(s0.data_ptr(), tiles, c0, _lib.ptr(s1), tiles + 1 if c1 else 0, c1, B, H * W, 32, 1e-5,
+                                        g.data_ptr(), bt.data_ptr(), sc_ref.data_ptr(), sh_ref.data_ptr(), _lib.current_stream()))
+    kw = dict(x0=x0, c0=c0, x1=x1, c1=c1, batch=B, hin=H, win=W, ks=3, stride=1, ups=0, w=pack3(lib, w), n=cout, prologue=1,
+              bias=dev(bias), ld_out=cout, precision=1)
+    out_ref = torch.empty(B, H, W, cout, device="cuda")
+    run_conv(lib, sc=sc_ref, sh=sh_ref, out=out_ref, **kw)
+    # fused path: sc / sh start as NaN and are written by the kernel
+    sc, sh = torch.full((B, cin), float("nan"), device="cuda"), torch.full((B, cin), float("nan"), device="cuda")
+    out = torch.empty(B, H, W, cout, device="cuda")
+    run_conv(lib, sc=sc, sh=sh, out=out, gn_stats0=s0, gn_tiles0=tiles, gn_stats1=s1 if c1 else 0, gn_tiles1=tiles + 1 if c1 else 0,
+             gn_gamma=g, gn_beta=bt, gn_eps=1e-5, gn_groups=32, **kw)
+    assert (sc - sc_ref).abs().max() < 1e-6 and (sh - sh_ref).abs().max() < 1e-6
+    assert (out - out_ref).abs().max() < 1e-5
+    assert (out.cpu() - nhwc(ref)).abs().max() < TOL_OP
+    # refused where the kernel cannot do it
+    with pytest.raises(RuntimeError, match="fused GroupNorm"):
+        run_conv(lib, sc=sc, sh=sh, out=out, gn_stats0=s0, gn_tiles0=tiles, gn_gamma=g, gn_beta=bt, gn_eps=1e-5, gn_groups=32,
+                 **dict(kw, precision=0))
