@@ -43,7 +43,18 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
   __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);   // [RING stages][4 arrays][64 rows][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  // XCD-aware block order: workgroup ids go round-robin over the 8 XCDs, and every query tile of one (batch, head) streams the SAME
+  // K / V^T planes (512 KB at L = 1024) - with the natural (qt, h, b) order its 8 query tiles sat on 8 different XCDs and each L2
+  // fetched its own copy (FETCH_SIZE 141 MB for 50 MB of planes).  The remap gives XCD x the contiguous id range
+  // [x*n/8, (x+1)*n/8), i.e. all query tiles of a (batch, head) share one L2.
+  const int nqt = p.L / (NWAVES * 32);
+  int lid;
+  {
+    const int orig = blockIdx.x, nwg = gridDim.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  }
+  const int qt = lid % nqt, h = (lid / nqt) % p.H, b = lid / (nqt * p.H);
 #ifdef PF_TRACE
   const bool trace_on = tid == 0 && qt == 1 && h == 1 && b == 1;
   int tslot = 0;
@@ -256,8 +267,8 @@ int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, 
     PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf3_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
     done = true;
   }
-  if (wide) hipLaunchKernelGGL((attn_bf3_kernel<8, 4>), dim3(l / 256, n_heads, batch), dim3(512), 4 * 32768, stream, p);
-  else hipLaunchKernelGGL((attn_bf3_kernel<4, 2>), dim3(l / 128, n_heads, batch), dim3(256), 2 * 32768, stream, p);
+  if (wide) hipLaunchKernelGGL((attn_bf3_kernel<8, 4>), dim3((l / 256) * n_heads * batch), dim3(512), 4 * 32768, stream, p);
+  else hipLaunchKernelGGL((attn_bf3_kernel<4, 2>), dim3((l / 128) * n_heads * batch), dim3(256), 2 * 32768, stream, p);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }
