@@ -175,3 +175,18 @@ def read_smf(path: str):
             tracks.append(notes)
         pos = end
     return tracks, lyrics, division, tempo
+
+
+def check_prmat2c_integrity(prmat2c, is_custom_round: bool = False) -> float:
+    """ref:utils.py:402-430 - fraction of "orphan" sustain cells: a cell whose sustain rounds to > 0 although neither the onset nor
+    the sustain of the same key rounded to > 0 one step earlier (or it sits in step 0) counts as an error AND as a note; every
+    onset that rounds to > 0 counts as a note; the result is errors / notes.  ``int(round(v)) > 0`` on a float32 is ``v > 0.5``
+    (round-half-even), ``custom_round`` is ``0.95 < v < 1.05`` (ref:utils.py:395-399).  Vectorised; runs where the tensor lives."""
+    x = torch.as_tensor(np.asarray(prmat2c) if not isinstance(prmat2c, torch.Tensor) else prmat2c).detach().float()
+    on = ((x[:, 0] > 0.95) & (x[:, 0] < 1.05)) if is_custom_round else (x[:, 0] > 0.5)
+    sus = ((x[:, 1] > 0.95) & (x[:, 1] < 1.05)) if is_custom_round else (x[:, 1] > 0.5)
+    prev = torch.zeros_like(sus)
+    prev[:, 1:] = on[:, :-1] | sus[:, :-1]
+    err = int((sus & ~prev).sum())
+    total = err + int(on.sum())
+    return float(err / total)

@@ -61,3 +61,15 @@ def test_smf_writer_empty_and_overlap(tmp_path):
     midi.write_smf(path, [notes])
     tracks, _, _, _ = midi.read_smf(path)
     assert sorted(tracks[0]) == [(60, 0, 440), (60, 220, 660)]
+
+
+def test_check_prmat2c_integrity_vs_reference(golden):
+    """utils.check_prmat2c_integrity (ref:utils.py:402-430) - the product's vectorised form against values the reference's own
+    function returned for the seeded images (tools/make_goldens_notes.py)."""
+    from polyffusion_amd import midi, synth
+    g = golden("notes.npz")
+    for name in ("a", "b", "c"):
+        n, _, steps, _ = (int(v) for v in g[f"{name}_shape"])
+        x = synth.prmat2c_image(int(g[f"{name}_seed"]), n, steps)
+        assert abs(midi.check_prmat2c_integrity(x) - float(g[f"{name}_integrity"])) < 1e-12
+        assert abs(midi.check_prmat2c_integrity(x, is_custom_round=True) - float(g[f"{name}_integrity_custom"])) < 1e-12

@@ -72,6 +72,8 @@ def main():
         x = synth.prmat2c_image(seed, n, steps)
         out[f"{name}_seed"], out[f"{name}_shape"] = seed, np.array(x.shape)
         out[f"{name}_prmat"] = utils.prmat2c_to_prmat(x)
+        out[f"{name}_integrity"] = utils.check_prmat2c_integrity(x)                       # utils.py:402-430
+        out[f"{name}_integrity_custom"] = utils.check_prmat2c_integrity(x, is_custom_round=True)
         mask = (np.random.Generator(np.random.PCG64(seed + 100)).random((n, 2, steps, 128)) < 0.5).astype(np.float32)
         for tag, kw in (("plain", {}), ("mask", {"inp_mask": mask}), ("custom", {"is_custom_round": True})):
             utils.prmat2c_to_midi_file(x, "unused.mid", **kw)
