@@ -45,6 +45,13 @@ def dummy_cond_input(length, params):
     return prmat2c, None, chord, prmat
 
 
+def get_blurry_image(img: torch.Tensor, ratio: float = 1 / 8) -> torch.Tensor:
+    """``utils.py:552-567``: bicubic down by ``ratio``, nearest back up, clipped to [0, 1] - the ``cond_concat`` image of the
+    ``concat_blurry`` variant (``inference_sdf.py:797-803``).  Preparation of an input, not part of the step loop: torch ops."""
+    small = torch.nn.functional.interpolate(img, scale_factor=ratio, mode="bicubic")
+    return torch.nn.functional.interpolate(small, scale_factor=1 / ratio, mode="nearest").clip(0, 1)
+
+
 def get_autoreg_data(data: torch.Tensor, split_dim: int = 1) -> torch.Tensor:
     """(second half of item i, first half of item i+1): the half-shifted stream for odd runs."""
     steps = data.shape[split_dim]
@@ -471,6 +478,11 @@ def main(argv=None):
         bars = [int(v) for v in args.bar_list.split(",")] if args.bar_list else None
         mask = get_mask(orig, args.inpaint_type, bars).to(orig.device)
 
+    if params.get("concat_blurry", False):
+        # inference_sdf.py:797-803 - the denoiser of this variant takes cat([x, blurry image], 1); the generation entry points of
+        # Experiments accept cond_concat, the batched multi-song driver below does not carry it
+        raise SystemExit("params.concat_blurry: use Experiments.generate/inpaint(cond_concat=get_blurry_image(prmat2c, params.concat_ratio)); "
+                         "the reference's own training path for this variant ends in exit(0) (models/model_sdf.py:227-229)")
     S, B = args.num_generate, cond.shape[0]
     say(f"generating {S} song(s) x {B} segment(s) with uncond_scale = {args.uncond_scale} on {world} GPU(s)")
     gen, expmt = generate_songs(model, params, args, cond, cond_mid, orig, mask, seed, rank, world)

@@ -83,3 +83,12 @@ def test_oracle_predict_matches_reference(golden, tag):
     want = g[f"pred_{tag}_out"]
     assert out.shape == want.shape
     assert float((out - torch.from_numpy(want)).abs().max()) <= 2e-5
+
+
+def test_get_blurry_image(golden):
+    from polyffusion_amd.inference_sdf import get_blurry_image
+    g = golden("orchestration.npz")
+    img = torch.from_numpy(g["blurry_in"])
+    for tag, ratio in (("r8", 1 / 8), ("r4", 0.25)):
+        got = get_blurry_image(img.clone(), ratio)
+        assert got.shape == g[f"blurry_{tag}"].shape and float((got - torch.from_numpy(g[f"blurry_{tag}"])).abs().max()) <= 1e-6

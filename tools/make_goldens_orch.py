@@ -143,6 +143,13 @@ def main():
     run("autoreg_ddim", mddim, dd, 304, cond_mid=cond_mid.clone(), autoreg=True, uncond_scale=3.0,
         orig=orig.clone(), mask=mask.clone())
 
+    # ---- get_blurry_image (utils.py:552-567): the cond_concat image of the concat_blurry variant (inference_sdf.py:797-803)
+    import utils as ref_utils   # importable with the stubs of import_reference()
+    img = torch.from_numpy((rng.random((2, 2, 128, 128)) < 0.05).astype(np.float32))
+    g["blurry_in"] = img.numpy()
+    for tag, ratio in (("r8", 1 / 8), ("r4", 0.25)):
+        g[f"blurry_{tag}"] = ref_utils.get_blurry_image(img.clone(), ratio).numpy()
+
     os.makedirs(OUT, exist_ok=True)
     save("orchestration.npz", **g)
 
