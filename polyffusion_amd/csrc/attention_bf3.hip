@@ -255,20 +255,15 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
 int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, hipStream_t stream) {
   PF_REQUIRE(planes && (o || o_planes) && batch > 0 && n_heads > 0 && l > 0 && l % 128 == 0, "attention_bf3: L must be a positive multiple of 128");
   AttnP3 p{static_cast<const __bf16*>(planes), o, ldo, static_cast<__bf16*>(o_planes), batch, n_heads, l, 0.125f};
-  // 256-query workgroups when that still gives every CU one (and the tile count suits the 4-stage ring)
-  // Measured on MI355X (B=16, L=1024): the 8-wave form loses - its waves run S / softmax / PV in lockstep behind one barrier,
-  // so the matrix pipe idles during every softmax, while two independent 4-wave workgroups per CU drift apart and fill
-  // each other's gaps.  Kept for experiments (PF_ATTN_WIDE=1).
-  static const bool want_wide = getenv("PF_ATTN_WIDE") && atoi(getenv("PF_ATTN_WIDE")) != 0;
-  const bool wide = want_wide && l % 256 == 0 && (l / 256) * n_heads * batch >= 192;
+  // (an 8-wave / 256-query form - half the K/V^T tile traffic per query - was measured and lost: its waves run S / softmax / PV in
+  // lockstep behind one barrier, so the matrix pipe idles during every softmax, while two independent 4-wave workgroups per CU drift
+  // apart and fill each other's gaps)
   static bool done = false;
   if (!done) {
     PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf3_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768));
-    PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf3_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
     done = true;
   }
-  if (wide) hipLaunchKernelGGL((attn_bf3_kernel<8, 4>), dim3((l / 256) * n_heads * batch), dim3(512), 4 * 32768, stream, p);
-  else hipLaunchKernelGGL((attn_bf3_kernel<4, 2>), dim3((l / 128) * n_heads * batch), dim3(256), 2 * 32768, stream, p);
+  hipLaunchKernelGGL((attn_bf3_kernel<4, 2>), dim3((l / 128) * n_heads * batch), dim3(256), 2 * 32768, stream, p);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }

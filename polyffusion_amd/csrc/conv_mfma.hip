@@ -243,10 +243,6 @@ int conv_pick_tile(const pf_conv_args& a) {
   const int npad = (a.n + 63) / 64 * 64;
   const int mt128 = a.ks == 1 ? a.batch * hout * cdiv(wout, 128) : a.batch * cdiv(hout, 8) * cdiv(wout, 16);
   if (a.ks == 3 && a.stride == 2) return 2;
-  {  // bf16x3 3x3: 16x16-pixel tiles with 8 waves halve the weight bytes fetched per MFMA (the L2->CU pipe is the bound)
-    static const int force = getenv("PF_TILE") ? atoi(getenv("PF_TILE")) : -1;
-    if (force >= 0 && !(force == 3 && (a.precision != PF_PREC_BF16X3 || a.ks != 3))) return force;
-  }
   if (npad % 128 == 0 && mt128 * (npad / 128) >= (a.precision == PF_PREC_BF16X3 && a.ks == 3 ? 256 : 512)) return 0;   // bf16x3 3x3: the wide tile + split-K beats twice as many narrow tiles
   if (mt128 * (npad / 64) >= 512) return 1;
   return 2;
@@ -254,7 +250,7 @@ int conv_pick_tile(const pf_conv_args& a) {
 void conv_tile_shape(const pf_conv_args& a, int tile, int* th, int* tw) {
   if (a.ks == 1) { *th = 1; *tw = tile == 2 ? 64 : 128; }
   else if (a.stride == 2) { *th = 4; *tw = 16; }
-  else { *th = tile == 2 ? 4 : (tile == 3 ? 16 : 8); *tw = 16; }
+  else { *th = tile == 2 ? 4 : 8; *tw = 16; }
 }
 // split-K (bf16x3 3x3 only): layers whose tile grid cannot fill the chip (the 16x16 level at batch 16, most levels at
 // small batch) run ksplit K-slices per tile and a reduce kernel that also applies the epilogue
