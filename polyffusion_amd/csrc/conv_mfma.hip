@@ -243,7 +243,10 @@ int conv_pick_tile(const pf_conv_args& a) {
   const int npad = (a.n + 63) / 64 * 64;
   const int mt128 = a.ks == 1 ? a.batch * hout * cdiv(wout, 128) : a.batch * cdiv(hout, 8) * cdiv(wout, 16);
   if (a.ks == 3 && a.stride == 2) return 2;
-  if (npad % 128 == 0 && mt128 * (npad / 128) >= (a.precision == PF_PREC_BF16X3 && a.ks == 3 ? 256 : 512)) return 0;   // bf16x3 3x3: the wide tile + split-K beats twice as many narrow tiles
+  // bf16x3 3x3: the wide tile + split-K beats twice as many narrow tiles; planes GEMMs (both operands direct-to-LDS): one 128x128 workgroup
+  // per CU beats two 128x64 ones as soon as every CU gets one (measured at M = 16384, N = 256: K = 256 18.1 -> 16.1 us, K = 1024 37.5 -> 33.9 us)
+  const bool wide_at_256 = a.precision == PF_PREC_BF16X3 && (a.ks == 3 || a.a_planes);
+  if (npad % 128 == 0 && mt128 * (npad / 128) >= (wide_at_256 ? 256 : 512)) return 0;
   if (mt128 * (npad / 64) >= 512) return 1;
   return 2;
 }
