@@ -167,3 +167,20 @@ def test_sharded_generation_equals_unsharded(autoreg):
     # more ranks than songs: the surplus ranks hold zero rows
     args1 = argparse.Namespace(**{**vars(args), "num_generate": 1})
     assert inference_sdf.generate_songs(model, p, args1, cond, cond_mid, None, None, 99, 1, 2)[0].shape[0] == 0
+
+
+def test_cli_hip_graph_gives_the_same_files(tmp_path):
+    """--hip_graph (one captured reverse step replayed) changes nothing in the output: DDPM with inpainting-style blend, 6 steps via
+    a short schedule in params.yaml, autoregressive over 2 segments (three sampling runs, each captured on its own)."""
+    run = run_dir(tmp_path, "pt")
+    p = yaml.safe_load((run / "params.yaml").read_text())
+    p["n_steps"] = 6
+    (run / "params.yaml").write_text(yaml.safe_dump(p))
+    outs = []
+    for flag in ([], ["--hip_graph"]):
+        out = tmp_path / ("g" if flag else "e")
+        argv = ["--chkpt_path", str(run / "chkpts" / "weights_best.pt"), "--synthetic", "--length", "2", "--autoreg", "--uncond_scale", "2.0",
+                "--seed", "5", "--output_dir", str(out)] + flag
+        assert inference_sdf.main(argv) == 0
+        outs.append(np.load(out / sorted(f for f in os.listdir(out) if f.endswith(".npy"))[0]))
+    assert outs[0].shape == (4, 2, 64, 128) and np.array_equal(outs[0], outs[1])
