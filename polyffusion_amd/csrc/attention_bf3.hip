@@ -42,7 +42,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);   // [RING stages][4 arrays][64 rows][64]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA destinations (M0) stay in SGPRs
   // XCD-aware block order: workgroup ids go round-robin over the 8 XCDs, and every query tile of one (batch, head) streams the SAME
   // K / V^T planes (512 KB at L = 1024) - with the natural (qt, h, b) order its 8 query tiles sat on 8 different XCDs and each L2
   // fetched its own copy (FETCH_SIZE 141 MB for 50 MB of planes).  The remap gives XCD x the contiguous id range

@@ -90,13 +90,14 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   static_assert(TOTW % NT == 0 && FM >= 1 && FN >= 1, "bad tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-  const int kg = KG == 1 ? 0 : threadIdx.x / NT;                       // wave group (K half)
+  const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x / NT);   // wave group (K half), wave-uniform
   unsigned char* smem_raw = smem_all + kg * conv_bf3_group_lds<KS, STRIDE, TH, TW, BN, SKIP>();
   __bf16* sAh = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sAl = sAh + APLANE;
   __bf16* sW = sAl + APLANE;               // [WRING bufs][4 k8][2 planes][BN][8]
 
-  const int tid = KG == 1 ? threadIdx.x : threadIdx.x % NT, lane = tid & 63, wave = tid >> 6;   // group-local
+  const int tid = KG == 1 ? threadIdx.x : threadIdx.x % NT, lane = tid & 63;   // group-local
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA destinations (M0) and tile roles stay in SGPRs
 #ifdef PF_TRACE
   const bool trace_on = (threadIdx.x == 0) && (blockIdx.x == 0 || blockIdx.x == 301 || blockIdx.x == gridDim.x - 1);
   const int tbase = blockIdx.x == 0 ? 0 : (blockIdx.x == 301 ? 2048 : 4096);

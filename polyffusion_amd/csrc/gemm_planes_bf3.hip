@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA destinations (M0) stay in SGPRs
   const int wm = wave >> 1, wn = wave & 1;
   const int nwg = gridDim.x;
   int lid;
