@@ -288,21 +288,26 @@ class DDIMSampler(DiffusionSampler):
             self._dev_cache[key] = (rows.to(device), torch.from_numpy(np.asarray(self.time_steps, dtype=np.int32)).to(device))
         return self._dev_cache[key]
 
-    def _paint_graph(self, x, cond, t_start, orig, mask, orig_noise, uncond_scale, uncond_cond, cond_concat):
-        """All t_start+1 steps of a deterministic (eta = 0) DDIM loop as replays of one captured step."""
+    def _paint_graph(self, x, cond, t_start, orig, mask, orig_noise, uncond_scale, uncond_cond, cond_concat, noisy: bool):
+        """All t_start+1 steps of a DDIM loop as replays of one captured step.  ``noisy``: every step of the range has sigma != 0
+        (eta > 0) and draws one noise tensor, in the eager loop's draw order; otherwise (eta = 0) no step draws."""
         lib, dev, B, n = self._lib, x.device, x.shape[0], x.numel()
         (table, taus), st = self._coef_table(dev), self._step_state(dev)
         xb = x.clone()
         tb = torch.empty(B, dtype=torch.long, device=dev)
+        nz = torch.empty_like(xb) if noisy else None
+        off = self.sample_offset * (n // B)
 
         def body():
             stream = _lib.current_stream()
             _lib.check(lib.pf_step_begin(st.data_ptr(), taus.data_ptr(), tb.data_ptr(), B, stream), "pf_step_begin")
             xin = xb if cond_concat is None else torch.cat([xb, cond_concat], dim=1)
             e_t = self.get_eps(xin, tb, cond, uncond_scale=uncond_scale, uncond_cond=uncond_cond)
-            _lib.check(lib.pf_ddim_step_dev(xb.data_ptr(), e_t.data_ptr(), None, _lib.ptr(orig), _lib.ptr(orig_noise), _lib.ptr(mask),
+            if noisy:
+                _lib.check(lib.pf_randn_dev(nz.data_ptr(), n, self.seed, st.data_ptr(), 0, off, stream), "pf_randn_dev")
+            _lib.check(lib.pf_ddim_step_dev(xb.data_ptr(), e_t.data_ptr(), _lib.ptr(nz), _lib.ptr(orig), _lib.ptr(orig_noise), _lib.ptr(mask),
                                             table.data_ptr(), st.data_ptr(), xb.data_ptr(), n, stream), "pf_ddim_step_dev")
-            _lib.check(lib.pf_step_end(st.data_ptr(), 0, stream), "pf_step_end")
+            _lib.check(lib.pf_step_end(st.data_ptr(), 1 if noisy else 0, stream), "pf_step_end")
 
         def restore():
             xb.copy_(x)
@@ -316,6 +321,8 @@ class DDIMSampler(DiffusionSampler):
             g.replay()
         e1.record()
         self.last_replay = (e0, e1, t_start + 1)
+        if noisy:
+            self._draws += t_start + 1
         return xb
 
     def _coef(self, index: int) -> _lib.DdimCoef:
@@ -385,9 +392,11 @@ class DDIMSampler(DiffusionSampler):
             orig, mask = orig.contiguous().float(), mask.contiguous().float()
             orig_noise = None if orig_noise is None else orig_noise.contiguous().float()
         time_steps = np.flip(self.time_steps[: t_start + 1])
-        if (self.graph and self.noise_fn is None and not bool((self.ddim_sigma[: t_start + 1] != 0).any())
-                and (orig is None or orig_noise is not None)):
-            return self._paint_graph(x, cond, int(t_start), orig, mask, orig_noise, uncond_scale, uncond_cond, cond_concat)
+        if self.graph and self.noise_fn is None and (orig is None or orig_noise is not None):
+            nonzero = self.ddim_sigma[: t_start + 1] != 0
+            if not bool(nonzero.any()) or bool(nonzero.all()):    # a mixed range would need a per-step decision on the host
+                return self._paint_graph(x, cond, int(t_start), orig, mask, orig_noise, uncond_scale, uncond_cond, cond_concat,
+                                         noisy=bool(nonzero.all()))
         for i, step in enumerate(time_steps):
             index = len(time_steps) - i - 1
             e_t = self._eps(x, cond, int(step), uncond_scale, uncond_cond, cond_concat)

@@ -142,6 +142,14 @@ def test_graph_replay_is_bit_identical_to_the_eager_loop(ldm):
         return d.paint(d.q_sample(orig, 6, x), cond, 6, orig=orig, mask=mask, orig_noise=x, uncond_scale=3.0, uncond_cond=uc)
 
     assert torch.equal(ddim(False), ddim(True))
+
+    def ddim_eta(graph):   # eta = 1: every step draws one noise tensor
+        d = DDIMSampler(ldm, 10, "quad", 1.0, seed=43, sample_offset=2, graph=graph)
+        x = d.randn((B, 2, 16, 16), cond.device)
+        return d.paint(x, cond, 7, uncond_scale=1.0, uncond_cond=uc), d._draws
+
+    (a, da), (b, db) = ddim_eta(False), ddim_eta(True)
+    assert da == db == 9 and torch.equal(a, b)
     # a second paint() on the same sampler object continues the draw sequence in both modes
     s1, s2 = SDFSampler(ldm, seed=1, graph=False), SDFSampler(ldm, seed=1, graph=True)
     for s in (s1, s2):
