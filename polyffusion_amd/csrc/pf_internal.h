@@ -61,7 +61,8 @@ int launch_ln_planes(const float* x, int rows, int c, float eps, const float* ga
 
 // stem / head convolutions (NCHW <-> NHWC at the ABI edge)
 int launch_conv_in(const float* x_nchw, const float* w /*[Cout][Cin][3][3]*/, const float* bias, float* out_nhwc,
-                   int batch, int cin, int cout, int h, int w_, hipStream_t stream);
+                   int batch, int cin, int cout, int h, int w_, hipStream_t stream, float* stats = nullptr);
+int launch_conv_in_stats_tiles(int cin, int cout, int h, int w_);   // per-sample statistics tiles launch_conv_in can emit (0: none)
 int launch_conv_out(const float* x_nhwc, const float* sc, const float* sh, const float* w /*[Cout][9][Cin]*/,
                     const float* bias, float* out_nchw, int batch, int cin, int cout, int h, int w_, hipStream_t stream);
 

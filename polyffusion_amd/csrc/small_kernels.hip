@@ -55,9 +55,10 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_in_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out, int B,
-                                                          int H, int W) {
+                                                          int H, int W, float* __restrict__ stats) {
   constexpr int K = CIN * 9, T = 16, TI = T + 2, COUT = 64;
   __shared__ float sx[CIN][TI][TI + 1];
+  __shared__ float sred[16][16][8];   // [pixel column][channel quad][4 sums | 4 sums of squares] (statistics only)
   const int tid = threadIdx.x;
   int bid = blockIdx.x;
   const int tilesx = (W + T - 1) / T, tilesy = (H + T - 1) / T;
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(256) void conv_in_reg_kernel(const float* __restric
   }
   __syncthreads();
   const int ox = tx * T + px;
-  if (ox >= W) return;
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ox < W) {
 #pragma unroll 4
   for (int py = 0; py < T; ++py) {
     const int oy = ty * T + py;
@@ -96,17 +98,38 @@ __global__ __launch_bounds__(256) void conv_in_reg_kernel(const float* __restric
           for (int j = 0; j < 4; ++j) acc[j] = fmaf(v, wr[j][ci * 9 + r * 3 + s2], acc[j]);   // order: ci, then tap
         }
     *reinterpret_cast<float4*>(out + (((size_t)b * H + oy) * W + ox) * COUT + cq * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ssum[j] += acc[j]; ssq[j] += acc[j] * acc[j]; }
+  }
+  }
+  // per-tile channel (sum, sumsq) of what was stored, in the layout of the conv epilogues' statistics ([B][tiles][64][2]): the
+  // GroupNorm of the first ResBlock then needs no pass over the stem output (deterministic: fixed reduction order)
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sred[px][cq][j] = ssum[j]; sred[px][cq][4 + j] = ssq[j]; }
+    __syncthreads();
+    if (tid < COUT) {
+      const int q = tid >> 2, j = tid & 3;
+      float a = 0.f, qq = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { a += sred[c][q][j]; qq += sred[c][q][4 + j]; }
+      float* dst = stats + (((size_t)b * (tilesx * tilesy) + ty * tilesx + tx) * COUT + tid) * 2;
+      dst[0] = a; dst[1] = qq;
+    }
   }
 }
 
+int launch_conv_in_stats_tiles(int cin, int cout, int h, int w_) { return (cin <= 2 && cout == 64) ? cdiv(h, 16) * cdiv(w_, 16) : 0; }
+
 int launch_conv_in(const float* x, const float* w, const float* bias, float* out, int batch, int cin, int cout, int h, int w_,
-                   hipStream_t stream) {
+                   hipStream_t stream, float* stats) {
+  PF_REQUIRE(!stats || launch_conv_in_stats_tiles(cin, cout, h, w_) > 0, "conv_in: statistics only from the register-weight kernel (cin <= 2, cout == 64)");
   PF_REQUIRE(cout % 4 == 0 && (size_t)cout * cin * 9 * 4 <= 64 * 1024, "conv_in: unsupported channel counts %d->%d", cin, cout);
   const size_t total = (size_t)batch * h * w_ * (cout / 4);
   if (cin <= 2 && cout == 64) {
     const int grid = batch * cdiv(h, 16) * cdiv(w_, 16);
-    if (cin == 1) hipLaunchKernelGGL(conv_in_reg_kernel<1>, dim3(grid), dim3(256), 0, stream, x, w, bias, out, batch, h, w_);
-    else hipLaunchKernelGGL(conv_in_reg_kernel<2>, dim3(grid), dim3(256), 0, stream, x, w, bias, out, batch, h, w_);
+    if (cin == 1) hipLaunchKernelGGL(conv_in_reg_kernel<1>, dim3(grid), dim3(256), 0, stream, x, w, bias, out, batch, h, w_, stats);
+    else hipLaunchKernelGGL(conv_in_reg_kernel<2>, dim3(grid), dim3(256), 0, stream, x, w, bias, out, batch, h, w_, stats);
     PF_CHECK_HIP(hipGetLastError());
     return PF_OK;
   }

@@ -684,11 +684,15 @@ static int run(pf_unet* u, Ctx& c, const float* x, const int64_t* t, const float
       switch (L.kind) {
         case 0: {
           float* od = c.palloc((size_t)B * H * W_ * L.cout);
+          // the stem conv emits the per-tile channel statistics of its output itself when it can (the usual 2 -> 64 stem);
+          // otherwise a statistics pass over the output follows
+          const int nst = launch_conv_in_stats_tiles(L.cin, L.cout, H, W_);
+          float* sb = nst ? c.palloc((size_t)B * nst * L.cout * 2) : nullptr;
           c.prof_begin(PF_K_SMALL, 2.0 * B * H * W_ * 9.0 * L.cin * L.cout);
-          if (!c.dry) small_launch(c, launch_conv_in(x, c.w(u->in_w), c.w(u->in_b), od, B, L.cin, L.cout, H, W_, c.s));
+          if (!c.dry) small_launch(c, launch_conv_in(x, c.w(u->in_w), c.w(u->in_b), od, B, L.cin, L.cout, H, W_, c.s, sb));
           c.prof_end();
           o.d = od; o.c = L.cout;
-          c.gn_partial(o, H * W_);
+          if (nst) { o.st = sb; o.nt = nst; } else c.gn_partial(o, H * W_);
           break;
         }
         case 1: o = run_res(c, L, a0, a1, H, W_, tb_all); break;
