@@ -143,3 +143,27 @@ def test_config5_autoreg_batched_over_8_songs(chd8bar):
     err = (gen[0].cpu() - ref).abs().max().item()
     print("config 5 (8 songs batched, 3 runs x 2 steps) song 0 max-abs-diff vs oracle:", err)
     assert err < TOL_TRAJ
+
+
+@pytest.mark.parametrize("name,d_cond", [("sdf_chd8bar_txt", 1536), ("sdf_chdvnl", 1152)])
+def test_other_shipped_param_sets_full_size(name, d_cond):
+    """The remaining params/*.yaml variants of the reference that change the denoiser's conditioning width: chord+txt (both encoders,
+    conditions concatenated: inference_sdf.py:777-795) and the un-encoded chord variant (cond = the flattened [32, 36] chord matrix,
+    models/model_sdf.py:102-106).  Full-size eps against the oracle, B = 2."""
+    from polyffusion_amd.inference_sdf import encode_conditions
+    p = preset(name)
+    assert p.d_cond == d_cond
+    m = synthetic_model(p)
+    m.ldm.eps_model.set_precision("bf16x3")
+    chd = torch.from_numpy(synth.chords(2, 71)).cuda()
+    prmat = torch.from_numpy(synth.prmat(2, 72)).cuda()
+    cond, _ = encode_conditions(m, p, chd, prmat, False)
+    assert cond.shape == (2, 1, d_cond)
+    x = torch.from_numpy(synth.gaussian((2, 2, 128, 128), 73)).cuda()
+    t = torch.tensor([17, 803]).cuda()
+    eps = m.ldm(x, t, cond)
+    with torch.no_grad():
+        ref = oracle_model(UNetConfig(d_cond=d_cond))(x.cpu(), t.cpu(), cond.cpu())
+    err = (eps.cpu() - ref).abs().max().item()
+    print(f"{name} eps max-abs-diff vs oracle:", err)
+    assert err < TOL_EPS
