@@ -2,13 +2,14 @@
 
 This module holds NO arithmetic.  It reproduces the *constructor logic* of the
 reference UNet (reference: polyffusion/stable_diffusion/model/unet.py:30-149)
-as a flat, data-only description that three consumers share:
+as a flat, data-only description that two consumers share:
 
 * ``polyffusion_amd.weights``  - names/shapes of every parameter (the reference
   ``state_dict`` key namespace, SURVEY.md Appendix D);
-* ``oracle.unet_ref``          - the CPU restatement walks it op by op;
 * ``tests``                    - to cross-check the C++ plan builder in
-  ``csrc/unet_plan.cpp`` (which re-derives the same walk natively).
+  ``csrc/unet.hip`` (which re-derives the same walk natively).
+
+(The CPU oracle does NOT use it: ``oracle/unet_ref.py`` derives its own block lists.)
 """
 from __future__ import annotations
 
