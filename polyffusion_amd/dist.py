@@ -26,11 +26,19 @@ def init_from_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # PF_LOCAL_DEVICE / PF_DIST_BACKEND exist for ONE purpose: running the N-rank code path on a box with a single GPU (every rank
+    # on device 0, gloo instead of RCCL, which refuses two ranks on one device) - tests/test_gpu_multirank.py.  Production: unset.
+    if "PF_LOCAL_DEVICE" in os.environ:
+        local = int(os.environ["PF_LOCAL_DEVICE"])
+    backend = os.environ.get("PF_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group(backend)
         else:
             dist.init_process_group("gloo")
     elif torch.cuda.is_available():
