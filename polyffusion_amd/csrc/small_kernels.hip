@@ -143,25 +143,26 @@ int launch_conv_in(const float* x, const float* w, const float* bias, float* out
 // ------------------------------------------------------------------ head: GN+SiLU -> conv3x3 -> few channels, NCHW out
 // 16x16 output pixels per block; the transformed 18x18 halo is staged in LDS 16 channels at a time.
 // Weights are pre-packed [Cout][9][Cin].
-template <int COUT_MAX>
+template <int COUT>
 __global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__ x, const float* __restrict__ sc,
                                                        const float* __restrict__ sh, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, int B, int Cin,
-                                                       int Cout, int H, int W) {
+                                                       int H, int W) {
+  // The weights are indexed with wave-uniform (compile-time after unrolling) offsets straight from global memory: hipcc turns those
+  // into scalar loads (s_load through the constant cache) and every FMA takes its weight from an SGPR - no LDS copy of the weights
+  // and no broadcast ds_read per FMA quad (the LDS port is what bounded the previous form: 3 ds_read_b128 per 8 FMAs).
   constexpr int T = 16, TI = T + 2, CK = 16, CP = CK + 4;
   __shared__ __attribute__((aligned(16))) float sx[TI * TI * CP];
-  extern __shared__ __attribute__((aligned(16))) float swt[];  // [Cout][9][Cin]
   const int tid = threadIdx.x;
   const int tilesx = (W + T - 1) / T, tilesy = (H + T - 1) / T;
   int bid = blockIdx.x;
   const int tx = bid % tilesx; bid /= tilesx;
   const int ty = bid % tilesy;
   const int b = bid / tilesy;
-  for (int i = tid; i < Cout * 9 * Cin; i += 256) swt[i] = w[i];
   const int py = tid / T, px = tid % T;
-  float acc[COUT_MAX];
+  float acc[COUT];
 #pragma unroll
-  for (int co = 0; co < COUT_MAX; ++co) acc[co] = 0.f;
+  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
   for (int c0 = 0; c0 < Cin; c0 += CK) {
     __syncthreads();
     for (int u = tid; u < TI * TI * (CK / 4); u += 256) {
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__
       *reinterpret_cast<float4*>(sx + pix * CP + c4 * 4) = v;
     }
     __syncthreads();
+    const float* wc = w + c0;   // [COUT][9][Cin], this chunk's 16 channels
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -187,12 +189,10 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__
         for (int c4 = 0; c4 < CK / 4; ++c4) {
           const float4 v = *reinterpret_cast<const float4*>(xp + c4 * 4);
 #pragma unroll
-          for (int co = 0; co < COUT_MAX; ++co) {
-            if (co < Cout) {
-              const float4 ww = *reinterpret_cast<const float4*>(swt + ((size_t)co * 9 + r * 3 + s) * Cin + c0 + c4 * 4);
-              acc[co] = fmaf(v.x, ww.x, acc[co]); acc[co] = fmaf(v.y, ww.y, acc[co]);
-              acc[co] = fmaf(v.z, ww.z, acc[co]); acc[co] = fmaf(v.w, ww.w, acc[co]);
-            }
+          for (int co = 0; co < COUT; ++co) {
+            const float* ww = wc + ((size_t)co * 9 + r * 3 + s) * Cin + c4 * 4;   // uniform address -> scalar loads
+            acc[co] = fmaf(v.x, ww[0], acc[co]); acc[co] = fmaf(v.y, ww[1], acc[co]);
+            acc[co] = fmaf(v.z, ww[2], acc[co]); acc[co] = fmaf(v.w, ww[3], acc[co]);
           }
         }
       }
@@ -200,18 +200,20 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__
   const int oy = ty * T + py, ox = tx * T + px;
   if (oy < H && ox < W) {
 #pragma unroll
-    for (int co = 0; co < COUT_MAX; ++co)
-      if (co < Cout) out[(((size_t)b * Cout + co) * H + oy) * W + ox] = acc[co] + bias[co];
+    for (int co = 0; co < COUT; ++co) out[(((size_t)b * COUT + co) * H + oy) * W + ox] = acc[co] + bias[co];
   }
 }
 
 int launch_conv_out(const float* x, const float* sc, const float* sh, const float* w, const float* bias, float* out, int batch,
                     int cin, int cout, int h, int w_, hipStream_t stream) {
   PF_REQUIRE(cout >= 1 && cout <= 4 && cin % 16 == 0, "conv_out: unsupported channel counts %d->%d", cin, cout);
-  const size_t lds = (size_t)cout * 9 * cin * sizeof(float);
-  PF_REQUIRE(lds <= 32 * 1024, "conv_out: weights do not fit LDS");
   const int grid = batch * cdiv(h, 16) * cdiv(w_, 16);
-  hipLaunchKernelGGL(conv_out_kernel<4>, dim3(grid), dim3(256), lds, stream, x, sc, sh, w, bias, out, batch, cin, cout, h, w_);
+  switch (cout) {
+    case 1: hipLaunchKernelGGL(conv_out_kernel<1>, dim3(grid), dim3(256), 0, stream, x, sc, sh, w, bias, out, batch, cin, h, w_); break;
+    case 2: hipLaunchKernelGGL(conv_out_kernel<2>, dim3(grid), dim3(256), 0, stream, x, sc, sh, w, bias, out, batch, cin, h, w_); break;
+    case 3: hipLaunchKernelGGL(conv_out_kernel<3>, dim3(grid), dim3(256), 0, stream, x, sc, sh, w, bias, out, batch, cin, h, w_); break;
+    default: hipLaunchKernelGGL(conv_out_kernel<4>, dim3(grid), dim3(256), 0, stream, x, sc, sh, w, bias, out, batch, cin, h, w_); break;
+  }
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }
