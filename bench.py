@@ -187,6 +187,36 @@ def small_batch_lines(model, params, steps, precision):
     return res
 
 
+def config3_line(model, params, steps=10):
+    """BASELINE.json configs[2]: DDIM 50 steps, uncond_scale 5 (classifier-free guidance: every step evaluates 2 x 32 = 64 samples), batch 32.
+    Timed through DDIMSampler.paint (eager): `steps` reverse steps from tau index 49."""
+    from polyffusion_amd.sampler import DDIMSampler
+    import time as _t
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B = 32
+    cond = model._encode_chord(torch.from_numpy(synth.chords(B, seed=888)).to(dev))
+    uc = -torch.ones(B, 1, params.d_cond, device=dev)
+    d = DDIMSampler(model.ldm, 50, "uniform", 0.0, seed=4)
+    shape = (B, params.out_channels, params.img_h, params.img_w)
+    x = d.randn(shape, dev)
+
+    def run(n):
+        xx = x
+        for i, step in enumerate(np.flip(d.time_steps)[:n]):
+            xx, _, _ = d.p_sample(xx, cond, None, int(step), 49 - i, uncond_scale=5.0, uncond_cond=uc)
+        return xx
+
+    run(2)
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    out = run(steps)
+    torch.cuda.synchronize()
+    dt = _t.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    return {"workload": "sdf_chd8bar DDIM 50-step, uncond_scale 5, batch 32 (64 UNet sample-evals per step), 1 GPU", "steps": steps,
+            "steps_per_s": round(steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3), "sample_evals_per_s": round(64 * steps / dt, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,6 +354,7 @@ def main():
         out["fp32_mode"] = fp32
     if rank == 0 and args.small_batch_steps > 0:
         out["small_batch"] = small_batch_lines(model, params, args.small_batch_steps, args.precision)
+        out["config3"] = config3_line(model, params)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params)
     if rank == 0:
