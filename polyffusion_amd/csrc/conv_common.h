@@ -238,6 +238,51 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
     }
     return;
   }
+  if constexpr (TH == 1) if (p.qkv && (p.N / 3) % BN == 0 && n0 >= 2 * (p.N / 3) && ox0 + TW <= p.Wout) {
+    // A tile inside the V third: V^T [head][d][token] runs along the tokens, which the accumulator layout holds four at a
+    // time per lane - 8-byte stores scattered over 64 d-rows per instruction.  Transpose the tile through LDS instead
+    // ([column][row], so a lane's four consecutive rows are one ds_write_b128) and store token-wise: 16 bytes per lane per
+    // plane, 256 contiguous bytes of one d-row per 16 lanes.
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    constexpr int BM = TW, pitchT = BM + 4;   // floats; +4: the 8 lanes of a b128 write group land on distinct banks
+    const int C = p.N / 3, L = p.Wout, H = C / 64;
+    const size_t MC = (size_t)p.B * L * C;
+    __bf16* base = static_cast<__bf16*>(p.qkv) + 4 * MC;
+    __syncthreads();
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+      const int cl = wn * WN + fn * 32 + (lane & 31);
+      const float bn = p.bias ? p.bias[n0 + cl] : 0.f;
+#pragma unroll
+      for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          f32x4 v4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v4[j] = acc[fm][fn][4 * rq + j] + bn;
+          *reinterpret_cast<f32x4*>(red + cl * pitchT + wm * WM + fm * 32 + 8 * rq + 4 * (lane >> 5)) = v4;
+        }
+    }
+    __syncthreads();
+    constexpr int NT = NWM * 128, CPR = BM / 8, ITER = BN * CPR / NT;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int item = tid + it * NT;
+      const int cl = item / CPR, c = item % CPR;
+      // stored positions 8c..8c+7 of this d-row: the first half of a 16-token block holds source quads 0 and 2, the second 1 and 3
+      const float* src = red + cl * pitchT + (c >> 1) * 16 + (c & 1) * 4;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src), q = *reinterpret_cast<const f32x4*>(src + 8);
+      const bf16x4_t ha = __builtin_convertvector(a, bf16x4_t), hq = __builtin_convertvector(q, bf16x4_t);
+      const bf16x4_t la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x4), bf16x4_t);
+      const bf16x4_t lq = __builtin_convertvector(q - __builtin_convertvector(hq, f32x4), bf16x4_t);
+      const int cc = n0 - 2 * C + cl;
+      const size_t o = (((size_t)b * H + cc / 64) * 64 + cc % 64) * L + ox0 + 8 * c;
+      *reinterpret_cast<bf16x8_t*>(base + o) = __builtin_shufflevector(ha, hq, 0, 1, 2, 3, 4, 5, 6, 7);
+      *reinterpret_cast<bf16x8_t*>(base + MC + o) = __builtin_shufflevector(la, lq, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    return;
+  }
   if constexpr (TH == 1) if (p.qkv) {
     // q|k|v planes for the bf16x3 attention: Q,K [token][C] and V^T [head][d][token] (middle token quads of every
     // 16-token block swapped, see attention_bf3.hip), each as a bf16 hi plane and a bf16 lo = bf16(x - hi) plane.
