@@ -41,10 +41,13 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // bf16 elements between two halo rows of one plane.  A pixel is 40 elements (80 B: consecutive pixels of a row are
 // conflict-free for ds_read_b128); a fragment's 32 pixels span TWO tile rows, and with the natural row pitch TWIN*40 the second
 // row's 16-byte slots land on the banks of the first (2-way conflict on every A read: SQ_LDS_BANK_CONFLICT was 35 % of the LDS
-// cycles).  Padding the row pitch to a multiple of 256 B makes the two rows tile the 64 banks exactly.
-template <int KS, int STRIDE, int TWIN>
+// cycles).  Padding the row pitch to a multiple of 256 B makes the two rows tile the 64 banks exactly.  Only for the 128-wide
+// tile: on the 64-wide one the padding costs the third workgroup per CU (55,296 B vs 53,376 B of 160 KiB / 3), and that tile -
+// K = 576 at the 128x128 level, half of a workgroup's life waiting for HBM - loses more to the missing wave than to the conflicts
+// (r128_64_64: 78 -> 70 us per launch).
+template <int KS, int STRIDE, int TWIN, int BN>
 constexpr int conv_bf3_row_pitch() {
-  return (KS != 1 && STRIDE == 1) ? (TWIN * 40 + 127) / 128 * 128 : TWIN * 40;
+  return (KS != 1 && STRIDE == 1 && BN >= 128) ? (TWIN * 40 + 127) / 128 * 128 : TWIN * 40;
 }
 
 // LDS bytes of one wave group: the main loop's halo image + weight ring, or the fused 1x1 phase's double buffers
@@ -52,7 +55,7 @@ template <int KS, int STRIDE, int TH, int TW, int BN, bool SKIP>
 constexpr size_t conv_bf3_group_lds() {
   constexpr int THIN = (TH - 1) * STRIDE + KS, TWIN = (TW - 1) * STRIDE + KS;
   constexpr int NABUF = (KS == 1) ? 2 : 1, WRING = (KS == 3) ? 3 : 2;
-  constexpr size_t main_b = (size_t)(2 * NABUF * THIN * conv_bf3_row_pitch<KS, STRIDE, TWIN>() + WRING * 8 * BN * 8) * 2;
+  constexpr size_t main_b = (size_t)(2 * NABUF * THIN * conv_bf3_row_pitch<KS, STRIDE, TWIN, BN>() + WRING * 8 * BN * 8) * 2;
   constexpr size_t skip_b = SKIP ? (size_t)(2 * 2 * TH * TW * 40 + 2 * 8 * BN * 8) * 2 : 0;
   return main_b > skip_b ? main_b : skip_b;
 }
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   constexpr int WM = BM / NWM, WN = BN / 2;
   constexpr int FM = WM / 32, FN = WN / 32;
   constexpr int PAD = (KS == 3) ? 1 : 0;   // KS == 2 (parity-folded upsampling conv): the pad depends on the parity, see iy0
-  constexpr int RP = conv_bf3_row_pitch<KS, STRIDE, TWIN>();   // bf16 elements per halo row (padded, see conv_bf3_row_pitch)
+  constexpr int RP = conv_bf3_row_pitch<KS, STRIDE, TWIN, BN>();   // bf16 elements per halo row (padded, see conv_bf3_row_pitch)
   constexpr int ABUF = THIN * RP;               // bf16 elements per halo image
   constexpr int APLANE = NABUF * ABUF;          // bf16 elements per A plane
   static_assert(TOTW % NT == 0 && FM >= 1 && FN >= 1, "bad tile");
