@@ -56,7 +56,8 @@ constexpr size_t conv_bf3_group_lds() {
   constexpr int THIN = (TH - 1) * STRIDE + KS, TWIN = (TW - 1) * STRIDE + KS;
   constexpr int NABUF = (KS == 1) ? 2 : 1, WRING = (KS == 3) ? 3 : 2;
   constexpr size_t main_b = (size_t)(2 * NABUF * THIN * conv_bf3_row_pitch<KS, STRIDE, TWIN, BN>() + WRING * 8 * BN * 8) * 2;
-  constexpr size_t skip_b = SKIP ? (size_t)(2 * 2 * TH * TW * 40 + 2 * 8 * BN * 8) * 2 : 0;
+  constexpr int NB1 = BN >= 128 ? 2 : 1;   // buffers of the fused 1x1 phase (see conv_bf3_kernel: the 64-wide tile keeps its third workgroup per CU)
+  constexpr size_t skip_b = SKIP ? (size_t)(2 * NB1 * TH * TW * 40 + NB1 * 8 * BN * 8) * 2 : 0;
   return main_b > skip_b ? main_b : skip_b;
 }
 
@@ -559,13 +560,16 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   if constexpr (SKIP) {
     // ---- fused 1x1 projection of a second tensor into the same accumulators (the ResBlock skip conv): one extra K range
     // over concat(sx0, sx1), no prologue, weights [K/8][plane][Npad][8].  Register-staged and double-buffered like the
-    // KS == 1 path, on the LDS the 3x3 loop has finished with; done by K-slice 0 only when the conv is split.
+    // KS == 1 path, on the LDS the 3x3 loop has finished with; done by K-slice 0 only when the conv is split.  The 64-wide tile
+    // single-buffers (one more barrier per 32-channel chunk): double buffers would be the tile's largest LDS user and cost it
+    // the third workgroup per CU.
     if (sidx == 0) {
+      constexpr int NB1 = BN >= 128 ? 2 : 1;
       constexpr int NA1 = BM * KQ / NT;          // float4 pieces per thread of a 32-channel slab of the tile's own pixels
       static_assert(BM * KQ % NT == 0, "tile pixels must divide over the block");
       __bf16* a1h = reinterpret_cast<__bf16*>(smem_raw);
-      __bf16* a1l = a1h + 2 * BM * PITCH;
-      __bf16* w1 = a1l + 2 * BM * PITCH;          // [2 bufs][4 k8][2 planes][BN][8]
+      __bf16* a1l = a1h + NB1 * BM * PITCH;
+      __bf16* w1 = a1l + NB1 * BM * PITCH;        // [NB1 bufs][4 k8][2 planes][BN][8]
       int goff[NA1];
 #pragma unroll
       for (int i = 0; i < NA1; ++i) {
@@ -614,8 +618,9 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       __syncthreads();
       for (int chunk = ch0; chunk < nch1; ++chunk) {
         if (chunk + 1 < nch1) load1(chunk + 1);
-        const int ao = ((chunk - ch0) & 1) * BM * PITCH;
-        const __bf16* cW = w1 + ((chunk - ch0) & 1) * (TOTW * 8) + wbase;
+        const int cur = NB1 == 2 ? ((chunk - ch0) & 1) : 0;
+        const int ao = cur * BM * PITCH;
+        const __bf16* cW = w1 + cur * (TOTW * 8) + wbase;
 #pragma unroll
         for (int s2 = 0; s2 < BK / 16; ++s2) {
           bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
@@ -642,7 +647,8 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
         }
-        if (chunk + 1 < nch1) store1((chunk + 1 - ch0) & 1);
+        if constexpr (NB1 == 1) __syncthreads();   // every wave has read the single buffer
+        if (chunk + 1 < nch1) store1(NB1 == 2 ? ((chunk + 1 - ch0) & 1) : 0);
         __syncthreads();
       }
     }
