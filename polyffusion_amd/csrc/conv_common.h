@@ -115,6 +115,26 @@ __device__ __forceinline__ size_t out_pixel(const ConvP& p, int b, int oy, int o
   return ((size_t)b * p.Hout + oy) * p.Wout + ox;
 }
 
+// 4x4 transpose across a lane quad: on entry lane i of the quad holds a[j] = M[i][j], on exit a[j] = M[j][i] (two butterfly
+// stages of quad-permute DPP moves; no LDS).  Used by the epilogue: a lane owns ONE channel of four consecutive pixels, and after
+// the transpose it owns FOUR consecutive channels of one pixel - a 16-byte store / residual load instead of four 4-byte ones.
+__device__ __forceinline__ void quad_transpose(f32x4& a, int lane) {
+  const bool p1 = lane & 1, p2 = lane & 2;
+  float s0 = p1 ? a[0] : a[1], s1 = p1 ? a[2] : a[3];
+  float r0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  float r1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
+  if (p1) { a[0] = r0; a[2] = r1; } else { a[1] = r0; a[3] = r1; }
+  s0 = p2 ? a[0] : a[2]; s1 = p2 ? a[1] : a[3];
+  r0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, true));         // quad_perm [2,3,0,1]
+  r1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, true));
+  if (p2) { a[0] = r0; a[1] = r1; } else { a[2] = r0; a[3] = r1; }
+}
+__device__ __forceinline__ float quad_sum(float v) {   // sum over the four lanes of a quad, every lane gets the total
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  return v;
+}
+
 // out[m][n] = acc + bias[n] + sbias[b][n] + res[m][n]   (or the GeGLU product), NHWC store.
 // When p.stats is set, the workgroup also emits the per-channel sum / sum-of-squares of what it stored, so that the
 // GroupNorm that consumes this tensor needs no pass over it (deterministic: lane pair -> LDS -> one writer per channel).
@@ -339,8 +359,91 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
 #pragma unroll
   for (int fn = 0; fn < FN; ++fn) { ssum[fn] = 0.f; ssq[fn] = 0.f; }
 
+  const bool wide = full && (p.ld_out & 3) == 0 && (!p.res || (p.ld_res & 3) == 0);   // workgroup-uniform
+  if (wide) {
+    // Interior tile, 16-byte accesses.  In the accumulator layout a lane owns one channel of 16 pixels (registers 4q..4q+3 = four
+    // consecutive pixels): 4-byte stores and residual loads, 16 of each per fragment, and it was their address path - not HBM -
+    // that bounded the epilogue (a timing variant moving the same bytes in 16-byte pieces: 72 -> 63 us on the 128x128-level
+    // conv).  A 4x4 transpose across each lane quad turns that into four consecutive channels of one pixel per lane: lane j of
+    // a quad ends up with pixel 8q + 4h + j, channels 4*(lane/4)..+3 of the fragment.  No LDS, no barrier.
+    const int j4 = lane & 3, cq = (lane & 31) & ~3;
+    f32x4 s1[FN], s2[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) { s1[fn] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[fn] = s1[fn]; }
+    f32x4 cb4[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+      const int n = n0 + wn * WN + fn * 32 + cq;
+      cb4[fn] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) cb4[fn] += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (sb) cb4[fn] += *reinterpret_cast<const f32x4*>(sb + n);
+      if (p.bias2) cb4[fn] += *reinterpret_cast<const f32x4*>(p.bias2 + n);
+    }
+    // one fragment row (FN fragments) at a time: its residual loads back to back, then transposes, adds and stores - bounds the
+    // in-flight temporaries to 16*FN registers (the epilogue must not need more VGPRs than the main loop)
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+      size_t m[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pp = wm * WM + fm * 32 + 8 * q + 4 * (lane >> 5) + j4;
+        m[q] = out_pixel(p, b, oy0 + pp / TW, ox0 + pp % TW);
+      }
+      f32x4 rr[4][FN];
+      if (p.res) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int fn = 0; fn < FN; ++fn)
+            rr[q][fn] = *reinterpret_cast<const f32x4*>(p.res + m[q] * p.ld_res + n0 + wn * WN + fn * 32 + cq);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+          f32x4 v = {acc[fm][fn][4 * q], acc[fm][fn][4 * q + 1], acc[fm][fn][4 * q + 2], acc[fm][fn][4 * q + 3]};
+          quad_transpose(v, lane);
+          v += cb4[fn];
+          if (p.res) v += rr[q][fn];
+          *reinterpret_cast<f32x4*>(p.out + m[q] * p.ld_out + n0 + wn * WN + fn * 32 + cq) = v;
+          s1[fn] += v; s2[fn] += v * v;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (p.stats) {   // workgroup-uniform
+      // a lane summed its four channels over pixels j (mod 4) of one half (h): quad + half-wave reduce, then waves through LDS
+#pragma unroll
+      for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = quad_sum(s1[fn][e]), c = quad_sum(s2[fn][e]);
+          a += __shfl_xor(a, 32); c += __shfl_xor(c, 32);
+          s1[fn][e] = a; s2[fn][e] = c;
+        }
+      __syncthreads();   // nobody is still reading the main loop's LDS images
+      if (lane < 32 && j4 == 0) {
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+          float* pr = red + (wm * BN + wn * WN + fn * 32 + cq) * 2;
+          *reinterpret_cast<f32x4*>(pr) = f32x4{s1[fn][0], s2[fn][0], s1[fn][1], s2[fn][1]};
+          *reinterpret_cast<f32x4*>(pr + 4) = f32x4{s1[fn][2], s2[fn][2], s1[fn][3], s2[fn][3]};
+        }
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.N) {
+        const int par = p.fold ? 4 : 1;      // a folded upsampling conv emits one statistics tile per (source tile, parity)
+        const int tile = ((oy0 / TH) * p.tiles_x + ox0 / TW) * par + (p.fold ? p.fold_py * 2 + p.fold_px : 0);
+        float* dst = p.stats + (((size_t)b * (p.tiles_x * p.tiles_y * par) + tile) * p.N + n0 + tid) * 2;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NWM; ++i) { a0 += red[(i * BN + tid) * 2 + 0]; a1 += red[(i * BN + tid) * 2 + 1]; }
+        dst[0] = a0; dst[1] = a1;
+      }
+    }
+    return;
+  }
   if (full) {
-    // interior tile: no per-element bounds checks, hoisted per-column terms
+    // interior tile whose row strides are not multiples of four floats: per-element form, hoisted per-column terms
     float cb[FN];
     int ncol[FN];
 #pragma unroll
