@@ -119,13 +119,15 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   }
   int q = 0;                           // KS == 2: output parity (py, px) = (q >> 1, q & 1); the four parities of a source
   if constexpr (KS == 2) { q = lid & 3; lid >>= 2; p.fold_py = q >> 1; p.fold_px = q & 1; }   // tile run together (shared halo in L2)
-  const int sidx = lid % p.ksplit;   // K-slice (fastest varying: the slices of a tile run together and share its halo in L2)
-  lid /= p.ksplit;
-  const int nti = lid % p.nt;
-  int mt = lid / p.nt;
-  const int tx = mt % p.tiles_x; mt /= p.tiles_x;
-  const int ty = mt % p.tiles_y;
-  const int b = mt / p.tiles_y;
+  int t = fdiv(lid, p.d_ks);
+  const int sidx = lid - t * p.ksplit;   // K-slice (fastest varying: the slices of a tile run together and share its halo in L2)
+  lid = t;
+  int mt = fdiv(lid, p.d_nt);
+  const int nti = lid - mt * p.nt;
+  t = fdiv(mt, p.d_tx);
+  const int tx = mt - t * p.tiles_x; mt = t;
+  const int b = fdiv(mt, p.d_ty);
+  const int ty = mt - b * p.tiles_y;
   const int n0 = nti * BN;
   const int oy0 = ty * TH, ox0 = tx * TW;
   // KS == 2: output row 2y+py reads source rows {y-1, y} (py = 0) or {y, y+1} (py = 1); same for columns
@@ -134,8 +136,11 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   const int cin = p.c0 + p.c1;
   const int K8 = cin / 8;
   const int nsl = p.ksplit * KG, sl = sidx * KG + kg;       // K slices: across workgroups (split-K) x across wave groups
-  const int cbeg = (cin / BK) * sl / nsl;                     // this wave group's K-slice [cbeg, cbeg + nchunk) in BK-channel chunks
-  const int nchunk = (cin / BK) * (sl + 1) / nsl - cbeg;
+  // this wave group's K-slice [cbeg, cbeg + nchunk) in BK-channel chunks (nsl is 1 or a power of two in every dispatch: shifts)
+  const bool pow2 = (nsl & (nsl - 1)) == 0;
+  const int nsh = 31 - __builtin_clz(nsl);
+  const int cbeg = pow2 ? ((cin / BK) * sl) >> nsh : (cin / BK) * sl / nsl;
+  const int nchunk = (pow2 ? ((cin / BK) * (sl + 1)) >> nsh : (cin / BK) * (sl + 1) / nsl) - cbeg;
 
   const int c4 = tid % KQ;
   int poff[NA];
@@ -732,6 +737,7 @@ static int launch3_cfg(ConvP& p, hipStream_t stream) {
   p.tiles_x = cdiv(p.Wout, TW);
   p.tiles_y = cdiv(p.Hout, TH);
   p.nt = cdiv(p.Npad, BN);
+  conv_fill_divs(p);
   auto kern = conv_bf3_kernel<KS, STRIDE, UPS, TH, TW, BN, PRO, NWM, SKIP, KG>;
   static bool attr_done = false;
   if (!attr_done) {

@@ -31,6 +31,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 
+// Division of a non-negative int (< 2^31) by a launch-time constant as multiply-high + shift: the tile decode at the top of every
+// workgroup otherwise runs four to six emulated integer divisions (no divide instruction: ~40 instructions each, ~2 k cycles
+// before the first load is issued).  mul == 0 encodes a divisor of 1.
+struct FastDiv { unsigned mul, shr; };
+static inline FastDiv make_fastdiv(int d) {
+  if (d <= 1) return FastDiv{0u, 0u};
+  unsigned l = 31u - (unsigned)__builtin_clz((unsigned)d);
+  if (d & (d - 1)) ++l;                                   // ceil(log2 d)
+  const unsigned p = 31u + l;
+  return FastDiv{(unsigned)(((1ull << p) + (unsigned)d - 1u) / (unsigned)d), p - 32u};
+}
+__device__ __forceinline__ int fdiv(int x, FastDiv f) { return f.mul ? (int)(__umulhi((unsigned)x, f.mul) >> f.shr) : x; }
+
 struct ConvP {
   const float* x0; const float* x1; int c0, c1;
   int B, Hin, Win, Hout, Wout;
@@ -41,6 +54,7 @@ struct ConvP {
   float* out; int ld_out;
   float* stats;   // optional [B][tiles][N][2]: per-tile, per-channel (sum, sum of squares) of the stored outputs
   int tiles_x, tiles_y, nt;
+  FastDiv d_tx, d_ty, d_nt, d_ks;   // reciprocals of tiles_x, tiles_y, nt, ksplit (conv_fill_divs)
   int fold, fold_py, fold_px;   // parity-folded upsampling conv: tiles walk the SOURCE grid, pixel (y, x) is stored at (2y+py, 2x+px)
   const float* sx0; const float* sx1; int sc0, sc1;   // fused 1x1 projection of a second tensor (ResBlock skip conv)
   const void* sw; const float* bias2;
@@ -51,6 +65,10 @@ struct ConvP {
   const float* gn_s0; const float* gn_s1; int gn_t0, gn_t1;
   const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_groups;
 };
+
+static inline void conv_fill_divs(ConvP& p) {
+  p.d_tx = make_fastdiv(p.tiles_x); p.d_ty = make_fastdiv(p.tiles_y); p.d_nt = make_fastdiv(p.nt); p.d_ks = make_fastdiv(p.ksplit);
+}
 
 // GroupNorm scale/shift of THIS workgroup's sample, computed by the consuming kernel itself instead of a separate finalize launch
 // (a 5 us launch between every two convolutions).  Same arithmetic as gn_finalize_tiles_kernel: the per-tile

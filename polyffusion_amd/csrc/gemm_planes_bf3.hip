@@ -33,10 +33,10 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  const int nti = lid % p.nt;
-  int mt = lid / p.nt;
-  const int tx = mt % p.tiles_x;
-  const int b = mt / p.tiles_x;
+  const int mt = fdiv(lid, p.d_nt);
+  const int nti = lid - mt * p.nt;
+  const int b = fdiv(mt, p.d_tx);
+  const int tx = mt - b * p.tiles_x;
   const int n0 = nti * BN, ox0 = tx * BM;
   const int K = p.c0, L = p.Wout;
   const size_t MK = (size_t)p.B * L * K;
@@ -170,6 +170,7 @@ static int launch_gp(ConvP& p, hipStream_t stream) {
   constexpr size_t ring = (size_t)RING * (2 * BM * 4 + 8 * BN) * 16, epi = (size_t)BM * (BN + 8) * 4;   // epi: planes-output transpose
   constexpr size_t lds = ring > epi ? ring : epi;
   p.tiles_x = cdiv(p.Wout, BM); p.tiles_y = 1; p.nt = cdiv(p.Npad, BN);
+  conv_fill_divs(p);
   auto kern = gemm_planes_kernel<BM, BN, RING>;
   static bool done = false;
   if (!done) { PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
