@@ -30,6 +30,7 @@ struct AttnP3 {
   float* o; int ldo; __bf16* o_planes;
   int B, H, L;
   float scale;
+  FastDiv d_nqt, d_h;     // reciprocals of the query tiles per (batch, head) and of H (tile decode without emulated divisions)
 };
 
 // NWAVES waves x 32 queries per workgroup share every K / V^T tile; RING tile stages in LDS (32 KB each).
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
     const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   }
-  const int qt = lid % nqt, h = (lid / nqt) % p.H, b = lid / (nqt * p.H);
+  const int bh = fdiv(lid, p.d_nqt), qt = lid - bh * nqt;
+  const int b = fdiv(bh, p.d_h), h = bh - b * p.H;
 #ifdef PF_TRACE
   const bool trace_on = tid == 0 && qt == 1 && h == 1 && b == 1;
   int tslot = 0;
@@ -255,7 +257,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
 
 int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, hipStream_t stream) {
   PF_REQUIRE(planes && (o || o_planes) && batch > 0 && n_heads > 0 && l > 0 && l % 128 == 0, "attention_bf3: L must be a positive multiple of 128");
-  AttnP3 p{static_cast<const __bf16*>(planes), o, ldo, static_cast<__bf16*>(o_planes), batch, n_heads, l, 0.125f};
+  AttnP3 p{static_cast<const __bf16*>(planes), o, ldo, static_cast<__bf16*>(o_planes), batch, n_heads, l, 0.125f,
+           make_fastdiv(l / 128), make_fastdiv(n_heads)};
   // (an 8-wave / 256-query form - half the K/V^T tile traffic per query - was measured and lost: its waves run S / softmax / PV in
   // lockstep behind one barrier, so the matrix pipe idles during every softmax, while two independent 4-wave workgroups per CU drift
   // apart and fill each other's gaps)
