@@ -455,22 +455,21 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
             });
           }
           if constexpr (k >= 3 * G && k < 4 * G) {     // X1: this tap's share of the halo arithmetic
+            if constexpr (tap == T0 && k == 3 * G) {
+              // first use of the halo registers in this chunk: the loads issued in tap 0 are older than the WRING-1 weight tiles
+              // issued since (tap T0's own refill comes after this group).  Unconditional - also in the last chunk, whose halo
+              // loads are never consumed - so that every path to a transform step passes the wait (tools/lint_asm.py checks it).
+              static_assert(T0 + 1 == WRING, "the count below assumes WRING-1 tiles were issued between tap 0 and tap T0");
+              asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WRING - 1) * NW) : "memory");
+              SB();
+            }
             if (has_next) {
               static_for<0, NA>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (tap == T0 + (i * TSPAN) / NA) {
                   static_for<0, 4>([&](auto sc_) {
                     constexpr int sub = decltype(sc_)::value;
-                    if constexpr (k - 3 * G == (sub * G) / 4) {
-                      if constexpr (i == 0 && sub == 0) {
-                        // first use of the halo registers in this chunk: the loads issued in tap 0 are older than the WRING-1
-                        // weight tiles issued since (tap T0's own refill comes after this group)
-                        static_assert(T0 + 1 == WRING, "the count below assumes WRING-1 tiles were issued between tap 0 and tap T0");
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WRING - 1) * NW) : "memory");
-                        SB();
-                      }
-                      transformSub(i, sub);
-                    }
+                    if constexpr (k - 3 * G == (sub * G) / 4) transformSub(i, sub);
                   });
                 }
               });
@@ -559,6 +558,14 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(ra[i]));
     asm volatile("" : "+v"(vsc), "+v"(vsh));
+    // Same for the fragment registers: the last tap's reads for a tap that never runs are still in flight when the loop exits,
+    // and to the compiler those values are dead - it used their registers for the accumulator copies of the loop-exit edge, i.e.
+    // BEFORE the wait above, and a late LDS return then overwrote an accumulator (seen as run-to-run differences once a change
+    // elsewhere altered the register assignment).  A use after the wait keeps the registers allocated until the data has landed.
+    #pragma unroll
+    for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(al[i]), "v"(ah[i]));
+    #pragma unroll
+    for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(bh[i]), "v"(bl[i]));
     __builtin_amdgcn_sched_barrier(0);
   }
 

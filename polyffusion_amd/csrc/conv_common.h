@@ -460,46 +460,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
     }
     return;
   }
-  if (full) {
-    // interior tile whose row strides are not multiples of four floats: per-element form, hoisted per-column terms
-    float cb[FN];
-    int ncol[FN];
-#pragma unroll
-    for (int fn = 0; fn < FN; ++fn) {
-      ncol[fn] = n0 + wn * WN + fn * 32 + (lane & 31);
-      cb[fn] = (p.bias ? p.bias[ncol[fn]] : 0.f) + (sb ? sb[ncol[fn]] : 0.f) + (p.bias2 ? p.bias2[ncol[fn]] : 0.f);
-    }
-    // per 32-row fragment: all residual loads back to back, then the adds and stores (out may alias nothing here, but the
-    // compiler cannot know: keeping a fragment's loads ahead of its stores lets them pipeline instead of serialising
-    // load -> add -> store per element).  One fragment at a time bounds the in-flight temporaries to 16*FN registers - the
-    // epilogue must not need more VGPRs than the main loop, or it costs the whole kernel a wave of occupancy.
-#pragma unroll
-    for (int fm = 0; fm < FM; ++fm) {
-      if (p.res) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int pp = wm * WM + fm * 32 + row;
-          const size_t m = out_pixel(p, b, oy0 + pp / TW, ox0 + pp % TW);
-#pragma unroll
-          for (int fn = 0; fn < FN; ++fn) acc[fm][fn][r] += p.res[m * p.ld_res + ncol[fn]];
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int pp = wm * WM + fm * 32 + row;
-        const size_t m = out_pixel(p, b, oy0 + pp / TW, ox0 + pp % TW);
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) {
-          const float v = acc[fm][fn][r] + cb[fn];
-          store_out(p, m * p.ld_out + ncol[fn], v);
-          ssum[fn] += v; ssq[fn] += v * v;
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else {
+  {   // edge tiles, GeGLU to fp32, row strides that are not multiples of four floats: per-element form with bounds checks
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
 #pragma unroll

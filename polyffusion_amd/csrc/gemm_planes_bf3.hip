@@ -161,6 +161,12 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
 #undef LD_BL
 #undef SB
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // the last iteration's fragment reads (for a chunk that never runs) are dead values to the compiler: keep their registers
+  // allocated until the wait above has passed, or a late LDS return lands in whatever was placed there (see conv_bf16x3.hip)
+  #pragma unroll
+  for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(al[i]), "v"(ah[i]));
+  #pragma unroll
+  for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(bh[i]), "v"(bl[i]));
   __syncthreads();
   conv_epilogue<1, BM, BN, FM, FN, 2>(p, acc, b, 0, ox0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem_raw));
 }

@@ -84,6 +84,24 @@ def main():
         for _ in range(3):
             _lib.check(lib.pf_conv2d(C.byref(a), st))
         torch.cuda.synchronize()
+        if os.environ.get("PF_DET"):   # determinism check: the same launch must reproduce its output bit for bit
+            out.zero_()   # (plane outputs cover only part of the buffer)
+            _lib.check(lib.pf_conv2d(C.byref(a), st))
+            torch.cuda.synchronize()
+            ref = out.clone()
+            bad = 0
+            for _ in range(8):
+                out.zero_()
+                _lib.check(lib.pf_conv2d(C.byref(a), st))
+                torch.cuda.synchronize()
+                ne = out.view(torch.int32) != ref.view(torch.int32)   # bit patterns: the random packed weights hold NaNs
+                if ne.any():
+                    bad += 1
+                    idx = ne.flatten().nonzero().flatten()
+                    print(f"   {int(ne.sum())} elements differ, first flat indices {idx[:6].tolist()} last {idx[-3:].tolist()} "
+                          f"(row {int(idx[0]) // n}, col {int(idx[0]) % n}); values {out.flatten()[idx[:3]].tolist()} vs {ref.flatten()[idx[:3]].tolist()}")
+            print(f"{name:18s} deterministic: {'yes' if bad == 0 else f'NO ({bad}/8 runs differ)'}")
+            continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         iters = 20
         e0.record()
