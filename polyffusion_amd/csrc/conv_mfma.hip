@@ -265,10 +265,6 @@ static int ksplit_wanted(const pf_conv_args& a) {
   conv_tile_shape(a, conv_pick_tile(a), &th, &tw);
   const int blocks = a.batch * cdiv(hout, th) * cdiv(wout, tw) * cdiv((a.n + 63) / 64 * 64, 64);
   const int nchunk = (a.c0 + a.c1) / 32;
-  {  // experiment hook
-    static const int force = getenv("PF_KSPLIT") ? atoi(getenv("PF_KSPLIT")) : 0;
-    if (force > 0) return (nchunk % force == 0) ? force : 1;
-  }
   if (blocks >= 256) return 1;   // one workgroup per CU already: measured, splitting further only adds the reduce pass
   int s = 1;
   while (s < 4 && blocks * s * 2 <= 1024 && nchunk % (s * 2) == 0) s *= 2;

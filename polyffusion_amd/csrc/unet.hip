@@ -432,9 +432,8 @@ struct Ctx {
   // convolution it feeds; at the 128x128 / 64x64 levels every consumer workgroup would re-read 32-64 KB, so the launch stays.
   struct GnRef { bool fused = false; const float* s0 = nullptr; const float* s1 = nullptr; int t0 = 0, t1 = 0; size_t g = 0, b = 0; float eps = 0.f; };
   GnRef gn(const Tn& x0, const Tn& x1, int hw, float eps, size_t g, size_t b_, float* sc, float* sh, bool fuse_ok = false) {
-    static const bool no_fuse = getenv("PF_NO_GN_FUSE") != nullptr;   // experiment hook
     const int cin_ = x0.c + x1.c;
-    if (fuse_ok && !no_fuse && u->precision == PF_PREC_BF16X3 && cin_ % 32 == 0 && cin_ <= 1024 && x0.nt <= 16 && (x1.c == 0 || x1.nt <= 16)) {
+    if (fuse_ok && u->precision == PF_PREC_BF16X3 && cin_ % 32 == 0 && cin_ <= 1024 && x0.nt <= 16 && (x1.c == 0 || x1.nt <= 16)) {
       GnRef r; r.fused = true; r.s0 = x0.st; r.t0 = x0.nt; r.s1 = x1.st; r.t1 = x1.nt; r.g = g; r.b = b_; r.eps = eps;
       return r;
     }
@@ -621,8 +620,7 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
     {
       pf_conv_args a = conv_base(ff, 4 * C, nullptr, 0, B, 1, hw, 1, c.w(t.ff2w), C, t2);
       a.bias = c.w(t.ff2b); a.res = t1; a.ld_res = C; a.a_planes = planes ? 1 : 0;
-      static const bool no_lp = getenv("PF_NO_LAST_PLANES") != nullptr;   // experiment hook
-      last_planes = planes && !no_lp && (i + 1 == L.tbs.size());
+      last_planes = planes && (i + 1 == L.tbs.size());
       if (last_planes) a.out_planes = c.dry ? (void*)1 : (void*)t2;   // only proj_out reads it: hand it over as planes
       c.conv(a, PF_K_GEMM);
     }
@@ -709,8 +707,7 @@ static int run(pf_unet* u, Ctx& c, const float* x, const int64_t* t, const float
           float* od = c.palloc((size_t)B * (H * 2) * (W_ * 2) * L.cout);
           pf_conv_args a = conv_base(a0.d, a0.c, nullptr, 0, B, H, W_, 3, c.w(L.w1), L.cout, od);
           a.ups = 1; a.bias = c.w(L.b1);
-          static const bool no_fold = getenv("PF_NO_UPFOLD") != nullptr;   // experiment hook: the 9-tap form
-          if (c.u->precision == PF_PREC_BF16X3 && L.wfold && L.cin % 32 == 0 && !no_fold) {
+          if (c.u->precision == PF_PREC_BF16X3 && L.wfold && L.cin % 32 == 0) {
             a.ups_fold = 1; a.precision = PF_PREC_BF16X3;
             c.conv(a, PF_K_CONV3, &o, true, c.dry ? nullptr : c.w(L.wfold));
           } else {

@@ -12,7 +12,8 @@ from run to run.  The sources now keep those registers allocated until the wait 
 The check walks the control-flow graph of every kernel (each basic block once per distinct in-flight state) with the two
 in-order counters modelled as FIFOs (lgkmcnt: LDS accesses; vmcnt: vector loads/stores incl. direct-to-LDS loads) and reports
 every instruction OUTSIDE inline asm that reads or writes a register a hidden load is still in flight to.  Scalar loads
-(out-of-order on lgkmcnt) are not modelled: the pipelined loops must not contain any.
+are not modelled: they share lgkmcnt, so a pending one only makes a hand-counted `lgkmcnt(N)` stricter (LDS accesses outstanding
+<= all outstanding <= N), never weaker.
 
 usage: python tools/lint_asm.py [file.s ...]      (no arguments: compiles the three sources to build/asm/ and checks them)
 exit status 1 when a violation is found.
