@@ -22,6 +22,10 @@ SHAPES = [
     ("r16_256+256_256", 16, 16, 16, 256, 256, 256, 3, 1, 0, 1),
     ("up64_128", 16, 64, 64, 128, 0, 128, 3, 1, 1, 0),
     ("down128_64", 16, 128, 128, 64, 0, 64, 3, 2, 0, 0),
+    # second conv of a channel-changing ResBlock: the 1x1 skip projection of concat(x, skip) fused in (mode 7: skip_c0, skip_c1)
+    ("rs128_64_64", 16, 128, 128, 64, 0, 64, 3, 1, 0, 1, 7, 128, 64),
+    ("rs64_128_128", 16, 64, 64, 128, 0, 128, 3, 1, 0, 1, 7, 256, 128),
+    ("rs32_256_256", 16, 32, 32, 256, 0, 256, 3, 1, 0, 1, 7, 256, 256),
     ("g1024_256_256", 16, 1, 1024, 256, 0, 256, 1, 1, 0, 0),
     ("g1024_256_768ln", 16, 1, 1024, 256, 0, 768, 1, 1, 0, 3),
     ("g1024_1024_256", 16, 1, 1024, 1024, 0, 256, 1, 1, 0, 0),
@@ -47,7 +51,7 @@ def main():
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
     lib = _lib.load()
     for name, B, H, W, c0, c1, n, ks, stride, ups, pro, *rest in SHAPES:
-        planes = bool(rest and rest[0])
+        planes = bool(rest and rest[0]) and rest[0] != 7
         if planes and not prec:
             continue
         if flt and flt not in name:
@@ -80,6 +84,11 @@ def main():
             a.res = 0
         if mode == 3:
             a.qkv_planes, a.res = out.data_ptr(), 0
+        if mode == 7:
+            sc0, sc1 = rest[1], rest[2]
+            sx0 = torch.randn(B, H, W, sc0, device="cuda"); sx1 = torch.randn(B, H, W, sc1, device="cuda")
+            sw = torch.randn(lib.pf_packed_gemm_weight_floats(n, sc0 + sc1, 1), device="cuda") * 0.01
+            a.skip_x0, a.skip_c0, a.skip_x1, a.skip_c1, a.skip_w, a.res = sx0.data_ptr(), sc0, sx1.data_ptr(), sc1, sw.data_ptr(), 0
         st = torch.cuda.current_stream().cuda_stream
         for _ in range(3):
             _lib.check(lib.pf_conv2d(C.byref(a), st))
@@ -111,7 +120,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
-        gf = 2.0 * B * ho * wo * n * cin * taps / 1e9
+        gf = 2.0 * B * ho * wo * n * (cin * taps + (rest[1] + rest[2] if mode == 7 else 0)) / 1e9
         print(f"{name:18s} {us:8.1f} us  {gf:7.2f} GF  {gf / us * 1e3:7.1f} TF/s")
 
 
