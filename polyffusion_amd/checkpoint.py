@@ -12,7 +12,8 @@ Two on-disk formats exist for trained Polyffusion models:
 Neither lightning nor omegaconf is needed to read them: a checkpoint is a torch zip archive whose pickle is
 decoded here by a RESTRICTED unpickler - tensors, plain containers and numbers are rebuilt as usual, every
 ``omegaconf.*`` / ``lightning*`` / ``pytorch_lightning*`` global is mapped to an inert stand-in that only records
-its state, and anything else is refused (no arbitrary code runs while loading a downloaded checkpoint).
+its state, and anything else is refused: the allowlist is exact (module, name) pairs - constructors of containers, numbers and
+tensors only - so no global that can reach an importer, a loader or a callable-by-name is ever handed to the pickle machine.
 """
 from __future__ import annotations
 
@@ -38,7 +39,15 @@ _ALLOWED = {
     # Python-2 names that protocol-2 pickles use for the same builtins (pickle's own fix_imports table)
     ("builtins", "long"): int, ("builtins", "unicode"): str, ("builtins", "NoneType"): type(None),
 }
-_TORCH_OK_MODULES = ("torch._utils", "torch.storage", "torch._tensor", "torch.serialization", "torch.nn.parameter")
+# torch's tensor-rebuild helpers, as EXACT (module, name) pairs.  Whole-module allowlists are not safe: torch.storage holds
+# `_load_from_bytes` (an unrestricted torch.load on attacker bytes) and torch._utils holds `_import_dotted_name` (any callable by name).
+_TORCH_OK_GLOBALS = {
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"),
+    ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_parameter_with_state"),
+    ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+    ("torch.serialization", "_get_layout"),
+    ("torch.nn.parameter", "Parameter"),
+}
 _TORCH_OK_NAMES = {"FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage",
                    "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "Size", "device", "dtype", "Tensor",
                    "float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8", "bool"}
@@ -73,7 +82,7 @@ class RestrictedUnpickler(pickle.Unpickler):
             return _standin_for(module, name)
         if (module, name) in _ALLOWED:
             return _ALLOWED[(module, name)]
-        if module in _TORCH_OK_MODULES or (module == "torch" and name in _TORCH_OK_NAMES):
+        if (module, name) in _TORCH_OK_GLOBALS or (module == "torch" and name in _TORCH_OK_NAMES):
             return super().find_class(module, name)
         if module == "typing" and name == "Any":   # OmegaConf's ContainerMetadata.ref_type
             return Any

@@ -60,6 +60,36 @@ def test_restricted_unpickler_refuses_code(tmp_path):
         checkpoint.load_lightning_ckpt(path)
 
 
+def _raw_ckpt(path, pickle_bytes):
+    """A torch zip archive whose data.pkl is `pickle_bytes` (what a hostile download would look like)."""
+    import zipfile
+    with zipfile.ZipFile(path, "w") as z:
+        z.writestr("archive/data.pkl", pickle_bytes)
+        z.writestr("archive/version", "3\n")
+        z.writestr("archive/byteorder", "little")
+
+
+@pytest.mark.parametrize("gadget", ["load_from_bytes", "import_dotted_name", "rebuild_from_type", "serialization_load"])
+def test_restricted_unpickler_refuses_torch_gadgets(tmp_path, gadget):
+    """globals INSIDE torch that reach an unrestricted loader or an arbitrary callable must be refused by name."""
+    import io
+    inner = io.BytesIO()
+    torch.save(torch.zeros(1), inner)
+    g = {"load_from_bytes": ("torch.storage", "_load_from_bytes", (inner.getvalue(),)),
+         "import_dotted_name": ("torch._utils", "_import_dotted_name", ("os.getcwd",)),
+         "rebuild_from_type": ("torch._tensor", "_rebuild_from_type_v2", ()),
+         "serialization_load": ("torch.serialization", "load", (inner.getvalue(),))}[gadget]
+    # protocol-2 pickle by hand: GLOBAL module name, args tuple, REDUCE - inside {"state_dict": {}, "hyper_parameters": <gadget>}
+    body = (b"\x80\x02}(X\n\x00\x00\x00state_dict}X\x10\x00\x00\x00hyper_parametersc"
+            + g[0].encode() + b"\n" + g[1].encode() + b"\n" + pickle.dumps(g[2], protocol=2)[2:-1] + b"Ru.")
+    path = str(tmp_path / "gadget.ckpt")
+    _raw_ckpt(path, body)
+    import pickletools
+    pickletools.dis(body, out=io.StringIO())   # the hand-made stream is a well-formed pickle
+    with pytest.raises(pickle.UnpicklingError, match="does not allow"):
+        checkpoint.load_lightning_ckpt(path)
+
+
 def test_pretrained_encoder_key_remaps():
     from polyffusion_amd.model_sdf import _strip
     ce = synth_chord_encoder_state(0)
