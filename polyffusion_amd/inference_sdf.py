@@ -319,12 +319,39 @@ def make_parser() -> ArgumentParser:
     return p
 
 
+def _packed_blobs(params, args, parts, chord_enc, txt_enc):
+    """Rank 0's half of ``load_model``: checkpoint (or synthetic) state_dicts -> packed host blobs, one per sub-model."""
+    from .checkpoint import load_checkpoint, split_state
+    states = {}
+    if args.synthetic_weights:
+        from .arch import UNetConfig
+        from .weights import synth_chord_encoder_state, synth_texture_encoder_state, synth_unet_state
+        states["unet"] = synth_unet_state(UNetConfig.from_params(params), 0)
+        if chord_enc is not None:
+            states["chord_enc"] = synth_chord_encoder_state(0, params.chd_input_dim, params.chd_hidden_dim, params.chd_z_dim)
+        if txt_enc is not None:
+            states["txt_enc"] = synth_texture_encoder_state(0, params.txt_emb_size, params.txt_hidden_dim, params.txt_z_dim,
+                                                            params.txt_num_channel)
+    else:
+        path = args.chkpt_path
+        if path and os.path.exists(f"{path}/chkpts/{args.chkpt_name}"):
+            path = f"{path}/chkpts/{args.chkpt_name}"
+        if not path or not (path.endswith(".pt") or path.endswith(".ckpt")):
+            raise SystemExit("--chkpt_path must name a legacy .pt or a Lightning .ckpt checkpoint (or a run directory holding chkpts/)")
+        states["unet"], states["chord_enc"], states["txt_enc"] = split_state(load_checkpoint(path)[0])
+    blobs = {}
+    for name, mod, _ in parts:
+        if not states.get(name):
+            raise SystemExit(f"checkpoint has no {name} weights")
+        blobs[name] = mod.pack_state_dict(states[name])
+    return blobs
+
+
 def load_model(params, args, rank: int = 0, world: int = 1) -> Polyffusion_SDF:
     """Assemble the model (``inference_sdf.py:536-557,702-734``).  Rank 0 reads the checkpoint (or generates the synthetic
     weights) and repacks it into the kernel-side blobs; with world > 1 the other ranks receive the packed blobs by ONE
     broadcast each (RCCL over xGMI) and never touch the file system - SURVEY.md 8e."""
     from . import _lib, dist as pfdist
-    from .checkpoint import load_checkpoint, split_state
     unet = build_unet(params)
     chord_enc, txt_enc = build_encoders(params)
     parts = [("unet", unet, unet.weight_bytes())]
@@ -332,32 +359,21 @@ def load_model(params, args, rank: int = 0, world: int = 1) -> Polyffusion_SDF:
         parts.append(("chord_enc", chord_enc, int(_lib.load().pf_encoder_weight_bytes(chord_enc._h))))
     if txt_enc is not None:
         parts.append(("txt_enc", txt_enc, int(_lib.load().pf_encoder_weight_bytes(txt_enc._h))))
-    states = {}
-    if rank == 0:
-        if args.synthetic_weights:
-            from .arch import UNetConfig
-            from .weights import synth_chord_encoder_state, synth_texture_encoder_state, synth_unet_state
-            states["unet"] = synth_unet_state(UNetConfig.from_params(params), 0)
-            if chord_enc is not None:
-                states["chord_enc"] = synth_chord_encoder_state(0, params.chd_input_dim, params.chd_hidden_dim, params.chd_z_dim)
-            if txt_enc is not None:
-                states["txt_enc"] = synth_texture_encoder_state(0, params.txt_emb_size, params.txt_hidden_dim, params.txt_z_dim,
-                                                                params.txt_num_channel)
-        else:
-            path = args.chkpt_path
-            if path and os.path.exists(f"{path}/chkpts/{args.chkpt_name}"):
-                path = f"{path}/chkpts/{args.chkpt_name}"
-            if not path or not (path.endswith(".pt") or path.endswith(".ckpt")):
-                raise SystemExit("--chkpt_path must name a legacy .pt or a Lightning .ckpt checkpoint (or a run directory holding chkpts/)")
-            states["unet"], states["chord_enc"], states["txt_enc"] = split_state(load_checkpoint(path)[0])
     dev = _dev()
+    blobs, failure = {}, None
+    if rank == 0:
+        # every failure of the load (bad path, missing sub-model, unexpected / mis-shaped key) happens on rank 0 only while the
+        # other ranks already wait for the blobs: catch it, tell them, and let every rank leave with the same message
+        try:
+            blobs = {name: blob.to(dev) for name, blob in _packed_blobs(params, args, parts, chord_enc, txt_enc).items()}
+        except (SystemExit, Exception) as e:   # noqa: BLE001 - re-raised below on every rank
+            failure = e
+    if pfdist.broadcast_int(0 if failure is None else 1) != 0:
+        if failure is not None:
+            raise failure
+        raise SystemExit("rank 0 could not load the model weights (see its message)")
     for name, mod, nbytes in parts:
-        if rank == 0:
-            if not states.get(name):
-                raise SystemExit(f"checkpoint has no {name} weights")
-            blob = mod.pack_state_dict(states[name]).to(dev)
-        else:
-            blob = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        blob = blobs[name] if rank == 0 else torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
         pfdist.broadcast_blob(blob, 0)
         mod.bind_packed(blob)
     return Polyffusion_SDF(build_ldm(params, unet), params.cond_type, params.cond_mode, chord_enc=chord_enc, txt_enc=txt_enc)

@@ -185,8 +185,11 @@ def check_prmat2c_integrity(prmat2c, is_custom_round: bool = False) -> float:
     x = torch.as_tensor(np.asarray(prmat2c) if not isinstance(prmat2c, torch.Tensor) else prmat2c).detach().float()
     on = ((x[:, 0] > 0.95) & (x[:, 0] < 1.05)) if is_custom_round else (x[:, 0] > 0.5)
     sus = ((x[:, 1] > 0.95) & (x[:, 1] < 1.05)) if is_custom_round else (x[:, 1] > 0.5)
+    # "previous cell empty" is `int(round(v)) == 0`, i.e. -0.5 <= v <= 0.5 under round-half-even: a NEGATIVE overshoot below -0.5
+    # rounds to -1 and counts as occupied upstream (custom_round only yields 0 / 1, so there it is just "not 1")
+    occ = (lambda v, r: r) if is_custom_round else (lambda v, r: (v > 0.5) | (v < -0.5))
     prev = torch.zeros_like(sus)
-    prev[:, 1:] = on[:, :-1] | sus[:, :-1]
+    prev[:, 1:] = occ(x[:, 0], on)[:, :-1] | occ(x[:, 1], sus)[:, :-1]
     err = int((sus & ~prev).sum())
     total = err + int(on.sum())
     return float(err / total)

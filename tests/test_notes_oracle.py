@@ -73,3 +73,18 @@ def test_check_prmat2c_integrity_vs_reference(golden):
         x = synth.prmat2c_image(int(g[f"{name}_seed"]), n, steps)
         assert abs(midi.check_prmat2c_integrity(x) - float(g[f"{name}_integrity"])) < 1e-12
         assert abs(midi.check_prmat2c_integrity(x, is_custom_round=True) - float(g[f"{name}_integrity_custom"])) < 1e-12
+
+
+def test_check_prmat2c_integrity_negative_overshoot(golden):
+    """`int(round(v)) == 0` is false below -0.5 (round(-0.7) == -1), so a negative overshoot in the previous cell makes the
+    next sustain cell a continuation upstream; pinned on a noisy image by the reference's own function."""
+    import numpy as np
+    from polyffusion_amd import midi, synth
+    g = golden("notes.npz")
+    n, _, steps, _ = (int(v) for v in g["neg_shape"])
+    seed = int(g["neg_seed"])
+    x = synth.prmat2c_image(seed, n, steps)
+    x = (x + 0.45 * np.random.Generator(np.random.PCG64(seed + 7)).standard_normal(x.shape)).astype(np.float32)
+    assert (x < -0.5).sum() > 100
+    assert abs(midi.check_prmat2c_integrity(x) - float(g["neg_integrity"])) < 1e-12
+    assert abs(midi.check_prmat2c_integrity(x, is_custom_round=True) - float(g["neg_integrity_custom"])) < 1e-12

@@ -65,6 +65,12 @@ def import_utils():
     return utils, PrettyMIDI
 
 
+def noisy_image(seed, n, steps):
+    """A seeded image plus N(0, 0.45) noise - values on both sides of -0.5, 0.5 and 1.05 (the test rebuilds it the same way)."""
+    x = synth.prmat2c_image(seed, n, steps)
+    return (x + 0.45 * np.random.Generator(np.random.PCG64(seed + 7)).standard_normal(x.shape)).astype(np.float32)
+
+
 def main():
     utils, PM = import_utils()
     out = {}
@@ -81,6 +87,12 @@ def main():
             rows = [(i, nt.pitch, nt.start, nt.end, nt.velocity) for i, ins in enumerate(midi.instruments) for nt in ins.notes]
             out[f"{name}_{tag}_notes"] = np.array(rows, dtype=np.float64).reshape(-1, 5)
             out[f"{name}_{tag}_ninstr"] = len(midi.instruments)
+    # raw sampler output overshoots on both sides: cells below -0.5 round to -1, which the reference counts as "occupied"
+    x = noisy_image(14, 2, 64)
+    assert (x < -0.5).sum() > 100
+    out["neg_seed"], out["neg_shape"] = 14, np.array(x.shape)
+    out["neg_integrity"] = utils.check_prmat2c_integrity(x)
+    out["neg_integrity_custom"] = utils.check_prmat2c_integrity(x, is_custom_round=True)
     np.savez_compressed(os.path.join(OUT, "notes.npz"), **out)
     print("notes.npz", os.path.getsize(os.path.join(OUT, "notes.npz")) // 1024, "KiB")
 
