@@ -187,6 +187,15 @@ int pf_ln_stats(const float* x, int rows, int c, float eps, float* mean, float* 
 /* LayerNorm applied and split into bf16 hi/lo planes [rows][c] | [rows][c] (the A operand of pf_conv2d with a_planes=1);
  * replaces pf_ln_stats + the LayerNorm GEMM prologue for the transformer block's q/k/v and GeGLU projections */
 int pf_ln_planes(const float* x, int rows, int c, float eps, const float* gamma, const float* beta, void* planes, void* stream);
+/* The feed-forward half of BasicTransformerBlock as ONE launch (unet_attention.py:119-124 `x = ff(norm3(x)) + x`, :296-333 FeedForward /
+ * GeGLU) for d_model 256, hidden 1024, bf16x3 arithmetic:  out = x + W2 . (a * gelu(g)) + b2 with [a|g] = W1 . LayerNorm(x) + b1.
+ * x fp32 [batch*l][256], l %% 64 == 0.  w1_bf16x3: the bf16x3 packing (pf_pack_gemm_weight_bf16x3) of ff.net.0.proj with its 2048 rows
+ * reordered value/gate-interleaved in blocks of 32 (row 64 i + j <- value 32 i + j, row 64 i + 32 + j <- gate 32 i + j), b1 in the same
+ * order; w2_bf16x3: packing of ff.net.2 ([256][1024]).  The result goes to fp32 `out` or, when out_planes != NULL, to bf16 hi/lo planes
+ * [M][256] | [M][256].  Bit-identical to pf_ln_planes + pf_conv2d(geglu, out_planes) + pf_conv2d(a_planes, res = x). */
+int pf_mlp_geglu_fused(const float* x, int batch, int l, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                       const void* w1_bf16x3, const float* b1, const void* w2_bf16x3, const float* b2,
+                       float* out, void* out_planes, void* stream);
 
 /* Implicit-GEMM convolution / linear on NHWC with fused prologue and epilogue (fp32 MFMA).
  *   ks 1|3, stride 1|2, ups 0|1 (nearest x2 folded into the input read, unet.py:236-238)

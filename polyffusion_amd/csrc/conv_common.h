@@ -116,7 +116,7 @@ __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_r
 // which dominated the GeGLU epilogue (64 evaluations per lane per tile).
 __device__ __forceinline__ float erf_as_f(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // hardware reciprocal (1 ulp): an IEEE division is ten instructions
   float pq = fmaf(1.061405429f, t, -1.453152027f);
   pq = fmaf(pq, t, 1.421413741f);
   pq = fmaf(pq, t, -0.284496736f);
@@ -136,17 +136,21 @@ __device__ __forceinline__ size_t out_pixel(const ConvP& p, int b, int oy, int o
 // 4x4 transpose across a lane quad: on entry lane i of the quad holds a[j] = M[i][j], on exit a[j] = M[j][i] (two butterfly
 // stages of quad-permute DPP moves; no LDS).  Used by the epilogue: a lane owns ONE channel of four consecutive pixels, and after
 // the transpose it owns FOUR consecutive channels of one pixel - a 16-byte store / residual load instead of four 4-byte ones.
-__device__ __forceinline__ void quad_transpose(f32x4& a, int lane) {
-  const bool p1 = lane & 1, p2 = lane & 2;
+__device__ __forceinline__ void quad_transpose_s1(f32x4& a, int lane) {   // first butterfly stage (lane ^ 1)
+  const bool p1 = lane & 1;
   float s0 = p1 ? a[0] : a[1], s1 = p1 ? a[2] : a[3];
   float r0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
   float r1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
   if (p1) { a[0] = r0; a[2] = r1; } else { a[1] = r0; a[3] = r1; }
-  s0 = p2 ? a[0] : a[2]; s1 = p2 ? a[1] : a[3];
-  r0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, true));         // quad_perm [2,3,0,1]
-  r1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void quad_transpose_s2(f32x4& a, int lane) {   // second stage (lane ^ 2)
+  const bool p2 = lane & 2;
+  float s0 = p2 ? a[0] : a[2], s1 = p2 ? a[1] : a[3];
+  float r0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, true));         // quad_perm [2,3,0,1]
+  float r1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, true));
   if (p2) { a[0] = r0; a[1] = r1; } else { a[2] = r0; a[3] = r1; }
 }
+__device__ __forceinline__ void quad_transpose(f32x4& a, int lane) { quad_transpose_s1(a, lane); quad_transpose_s2(a, lane); }
 __device__ __forceinline__ float quad_sum(float v) {   // sum over the four lanes of a quad, every lane gets the total
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));

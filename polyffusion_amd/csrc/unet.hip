@@ -526,6 +526,18 @@ static Tn run_res(Ctx& c, const Layer& L, const Tn& x0, const Tn& x1, int H, int
   return ot;
 }
 
+// The fused feed-forward launch (mlp_fused_bf3.hip) gives every 64-row tile to one four-wave workgroup that streams all 3 MB of ff
+// weights and occupies a whole CU (152 KB of LDS), so it runs in rounds of 256 tiles: measured 95 us per round against 113 us per
+// 16384 rows for the three launches it replaces (B = 16, L = 1024).  It is used when the last round is at least 85 % full
+// (B = 16 and B = 32 at the 32x32 level; never at the 16x16 level below B = 55).  PF_MLP_FUSED=0/1 forces it off / on.
+static bool mlp_fused_wanted(int C, int hw, int M) {
+  static const int force = [] { const char* e = getenv("PF_MLP_FUSED"); return e ? atoi(e) : -1; }();
+  if (C != 256 || hw % 64 != 0) return false;
+  if (force >= 0) return force != 0;
+  const int tiles = M / 64, rounds = (tiles + 255) / 256;
+  return tiles * 100 >= 85 * 256 * rounds;
+}
+
 static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const float* cond, const float* cross_all) {
   const int B = c.B, hw = H * W_, C = L.cin, M = B * hw, nh = c.u->cfg.n_heads, dh = C / nh, dc = c.u->cfg.d_cond;
   const float* x = xin.d;
@@ -604,6 +616,17 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
       std::swap(t1, t2);
     }
     // x = ff(LN3(x)) + x
+    last_planes = planes && (i + 1 == L.tbs.size());
+    if (planes && mlp_fused_wanted(C, hw, M)) {
+      // one launch: LayerNorm, GeGLU projection, output projection and residual per 64-row tile, hidden tensor kept on chip
+      c.prof_begin(PF_K_GEMM, 2.0 * M * ((double)C * 8 * C + 4.0 * C * C));
+      if (!c.dry && c.rc == PF_OK)
+        c.rc = launch_mlp_fused(t1, B, hw, c.w(t.n3g), c.w(t.n3b), 1e-5f, c.w(t.ff1w) + (size_t)C * 8 * C, c.w(t.ff1b),
+                                c.w(t.ff2w) + (size_t)4 * C * C, c.w(t.ff2b), t2, last_planes ? (void*)t2 : nullptr, c.s);
+      c.prof_end();
+      std::swap(t0, t2);
+      continue;
+    }
     if (planes) {
       c.lnp(t1, M, C, t.n3g, t.n3b, att);   // `att` has been consumed by to_out
       pf_conv_args a = conv_base(att, C, nullptr, 0, B, 1, hw, 1, c.w(t.ff1w), 8 * C, ff);
@@ -620,7 +643,6 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
     {
       pf_conv_args a = conv_base(ff, 4 * C, nullptr, 0, B, 1, hw, 1, c.w(t.ff2w), C, t2);
       a.bias = c.w(t.ff2b); a.res = t1; a.ld_res = C; a.a_planes = planes ? 1 : 0;
-      last_planes = planes && (i + 1 == L.tbs.size());
       if (last_planes) a.out_planes = c.dry ? (void*)1 : (void*)t2;   // only proj_out reads it: hand it over as planes
       c.conv(a, PF_K_GEMM);
     }
@@ -907,6 +929,11 @@ int pf_pack_upfold_weight_bf16x3(const float* w, int n, int k, void* dst) {
 }
 int pf_prmat2c_durations(const float* prmat2c, int n, int steps, int custom_round, int32_t* dur, void* stream) {
   return launch_prmat2c_durations(prmat2c, n, steps, custom_round, dur, (hipStream_t)stream);
+}
+int pf_mlp_geglu_fused(const float* x, int batch, int l, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                       const void* w1_bf16x3, const float* b1, const void* w2_bf16x3, const float* b2,
+                       float* out, void* out_planes, void* stream) {
+  return launch_mlp_fused(x, batch, l, ln_gamma, ln_beta, ln_eps, w1_bf16x3, b1, w2_bf16x3, b2, out, out_planes, (hipStream_t)stream);
 }
 int pf_ln_planes(const float* x, int rows, int c, float eps, const float* gamma, const float* beta, void* planes, void* stream) {
   return launch_ln_planes(x, rows, c, eps, gamma, beta, planes, (hipStream_t)stream);
