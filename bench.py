@@ -13,11 +13,12 @@ the timed region.  Rank 0 prints ONE JSON line; `value` is the whole-job aggrega
 weak scaling: every GPU denoises its own batch of 16).
 
 Extra objects (see DESIGN.md "Measurement"):
-  roofline     - the dominant kernel family (conv_mfma 3x3, fp32 MFMA): algorithmic FLOPs of its
-                 launches / their summed duration, measured with hipEvents around every launch
-                 on the launch stream in a separate profiled pass of the same workload.
-  cpu_baseline - the CPU oracle (same ATen ops as the reference) timed on this host's cores on a
-                 bounded sample (2 steps at batch 16), rank 0 and N == 1 only.
+  roofline     - the dominant kernel family (the 3x3 convolutions, conv_bf16x3.hip: error-compensated bf16 split on the
+                 bf16 matrix pipe, peak 2500/3 TFLOP/s fp32-equivalent): algorithmic FLOPs of its launches / their summed
+                 duration, measured with hipEvents around every launch on the launch stream in a separate profiled pass.
+  fp32_mode    - the same workload with exact fp32 MFMA (peak 157.3 TFLOP/s), printed beside the headline.
+  cpu_baseline - the CPU oracle (same ATen ops as the reference) timed on this host's cores: one warm-up step, a thread sweep,
+                 then the median of 3 steps at batch 16 with the best thread count; rank 0 and N == 1 only.
 """
 from __future__ import annotations
 

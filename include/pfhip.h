@@ -254,10 +254,9 @@ int pf_attention_bf16x3(const void* qkv_planes, float* o, int ldo, void* o_plane
 int pf_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                  int batch, int n_heads, int d_head, int lq, int lk, void* stream);
 
-/* Multi-GPU: one process per GPU.  The path shards over the batch with no exchange in the step
- * loop; the single collective (weight broadcast at start-up) is issued by the host through
- * torch.distributed (backend "nccl" = RCCL over xGMI) on the packed blob, so the library has
- * no communicator of its own. */
+/* Multi-GPU: one process per GPU.  The path shards over the batch with no exchange in the step loop; the single collective
+ * (weight broadcast at start-up) goes either through the host's torch.distributed (backend "nccl" = RCCL over xGMI) on the packed
+ * blob or through the library's own pf_comm_* entry points above (librccl opened with dlopen). */
 
 #ifdef __cplusplus
 }

@@ -55,9 +55,10 @@ class SDFSamplerRef:
         self.mean_x0_coef = self.beta * (ab_prev ** 0.5) / (1.0 - ab)
         self.mean_xt_coef = (1.0 - ab_prev) * ((1 - self.beta) ** 0.5) / (1.0 - ab)
 
-    def p_sample(self, x, c, step: int, uncond_scale=1.0, uncond_cond=None):
+    def p_sample(self, x, c, step: int, uncond_scale=1.0, uncond_cond=None, cond_concat=None):
         t = torch.full((x.shape[0],), int(step), dtype=torch.long)
-        e_t = get_eps(self.model, x, t, c, uncond_scale, uncond_cond)
+        # sampler_sdf.py:108-118 - the concat_blurry variant's denoiser sees cat([x, cond_concat], 1)
+        e_t = get_eps(self.model, x if cond_concat is None else torch.cat([x, cond_concat], dim=1), t, c, uncond_scale, uncond_cond)
         x0 = self.sqrt_recip_alpha_bar[step] * x - self.sqrt_recip_m1_alpha_bar[step] * e_t
         mean = self.mean_x0_coef[step] * x0 + self.mean_xt_coef[step] * x
         noise = 0 if step == 0 else self.noise_fn(tuple(x.shape))
@@ -70,17 +71,17 @@ class SDFSamplerRef:
         return self.sqrt_alpha_bar[index] * x0 + self.sqrt_1m_alpha_bar[index] * noise
 
     def paint(self, x, cond, t_start: int, orig=None, mask=None, orig_noise=None,
-              uncond_scale=1.0, uncond_cond=None, repaint_n=1):
+              uncond_scale=1.0, uncond_cond=None, repaint_n=1, cond_concat=None):
         for step in np.flip(self.time_steps[: t_start + 1]):
             step = int(step)
             if orig is None:
-                x, _, _ = self.p_sample(x, cond, step, uncond_scale, uncond_cond)
+                x, _, _ = self.p_sample(x, cond, step, uncond_scale, uncond_cond, cond_concat)
                 continue
             x_t = x
             for u in range(repaint_n):
                 noise = self.noise_fn(tuple(orig.shape)) if step > 0 else torch.zeros_like(orig)
                 x_kn = self.q_sample(orig, step, noise=noise)
-                x_unkn, _, _ = self.p_sample(x_t, cond, step, uncond_scale, uncond_cond)
+                x_unkn, _, _ = self.p_sample(x_t, cond, step, uncond_scale, uncond_cond, cond_concat)
                 x = x_kn * mask + x_unkn * (1 - mask)
                 if u < repaint_n - 1 and step > 0:
                     noise = self.noise_fn(tuple(orig.shape))
@@ -118,9 +119,9 @@ class DDIMSamplerRef:
         noise = 0.0 if sigma == 0.0 else self.noise_fn(tuple(x.shape))
         return (alpha_prev ** 0.5) * pred_x0 + dir_xt + sigma * noise, pred_x0
 
-    def p_sample(self, x, c, step: int, index: int, uncond_scale=1.0, uncond_cond=None):
+    def p_sample(self, x, c, step: int, index: int, uncond_scale=1.0, uncond_cond=None, cond_concat=None):
         t = torch.full((x.shape[0],), int(step), dtype=torch.long)
-        e_t = get_eps(self.model, x, t, c, uncond_scale, uncond_cond)
+        e_t = get_eps(self.model, x if cond_concat is None else torch.cat([x, cond_concat], dim=1), t, c, uncond_scale, uncond_cond)   # sampler_ddim.py:199-209
         x_prev, pred_x0 = self.get_x_prev_and_pred_x0(e_t, index, x)
         return x_prev, pred_x0, e_t
 
@@ -130,11 +131,11 @@ class DDIMSamplerRef:
         return self.ddim_alpha_sqrt[index] * x0 + self.ddim_sqrt_one_minus_alpha[index] * noise
 
     def paint(self, x, cond, t_start: int, orig=None, mask=None, orig_noise=None,
-              uncond_scale=1.0, uncond_cond=None, repaint_n=1):
+              uncond_scale=1.0, uncond_cond=None, repaint_n=1, cond_concat=None):
         time_steps = np.flip(self.time_steps[: t_start + 1])
         for i, step in enumerate(time_steps):
             index = len(time_steps) - i - 1
-            x, _, _ = self.p_sample(x, cond, int(step), index, uncond_scale, uncond_cond)
+            x, _, _ = self.p_sample(x, cond, int(step), index, uncond_scale, uncond_cond, cond_concat)
             if orig is not None:
                 x = self.q_sample(orig, index, noise=orig_noise) * mask + x * (1 - mask)
         return x
@@ -148,8 +149,9 @@ def get_autoreg_data(data: torch.Tensor, split_dim: int = 1) -> torch.Tensor:
 
 
 def predict(sampler, cond, d_cond: int, shape: List[int], t_idx: int, noise: torch.Tensor,
-            cond_mid=None, uncond_scale=1.0, autoreg=False, orig=None, mask=None, repaint_n=1):
-    """inference_sdf.py:202-303 (``Experiments.predict``) with the start noise injected."""
+            cond_mid=None, uncond_scale=1.0, autoreg=False, orig=None, mask=None, repaint_n=1, cond_concat=None):
+    """inference_sdf.py:202-303 (``Experiments.predict``) with the start noise injected.  ``cond_concat`` goes to every ``paint``
+    call WHOLE, as in the reference (:259-270): under ``autoreg`` only a one-segment batch fits the batch-1 runs."""
     B = cond.shape[0]
     uncond_cond = -torch.ones([B, 1, d_cond])
     if orig is None or mask is None:
@@ -157,7 +159,7 @@ def predict(sampler, cond, d_cond: int, shape: List[int], t_idx: int, noise: tor
     if not autoreg:
         xt = sampler.q_sample(orig, t_idx, noise)
         return sampler.paint(xt, cond, t_idx, orig=orig, mask=mask, orig_noise=noise,
-                             uncond_scale=uncond_scale, uncond_cond=uncond_cond, repaint_n=repaint_n)
+                             uncond_scale=uncond_scale, uncond_cond=uncond_cond, repaint_n=repaint_n, cond_concat=cond_concat)
     half = shape[2] // 2
     orig_mid, mask_mid, noise_mid = (get_autoreg_data(v, 2) for v in (orig, mask, noise))
     uc = uncond_cond[0:1]
@@ -170,7 +172,7 @@ def predict(sampler, cond, d_cond: int, shape: List[int], t_idx: int, noise: tor
             m_s[:, :, 0:half, :] = 1
         xt = sampler.q_sample(o_s, t_idx, n_s)
         x0 = sampler.paint(xt, c_s, t_idx, orig=o_s, mask=m_s, orig_noise=n_s,
-                           uncond_scale=uncond_scale, uncond_cond=uc, repaint_n=repaint_n)
+                           uncond_scale=uncond_scale, uncond_cond=uc, repaint_n=repaint_n, cond_concat=cond_concat)
         if idx == 0:
             gen.append(x0[:, :, 0:half, :])
         new_half = x0[:, :, half:, :]

@@ -167,6 +167,15 @@ class Experiments:
         S, B = cond.shape[0], cond.shape[1]
         shape = [S, B, p.out_channels, p.img_h, p.img_w]
         half = p.img_h // 2
+        if cond_concat is not None:
+            # the reference hands its WHOLE [B, ...] cond_concat to every batch-1 run (inference_sdf.py:259-270), which torch.cat
+            # only accepts for B == 1: the concat_blurry variant can run autoregressively on one-segment songs only
+            if cond_concat.dim() != 5 or cond_concat.shape[0] != S or cond_concat.shape[1] != B:
+                raise RuntimeError(f"predict_songs: cond_concat must be [S, B, C, H, W] = [{S}, {B}, ...], got {tuple(cond_concat.shape)}")
+            if B != 1:
+                raise RuntimeError(f"Sizes of tensors must match except in dimension 1. Expected size 1 but got size {B} for tensor number 1 "
+                                   "in the list. (cond_concat of a multi-segment song under --autoreg, as in the reference)")
+            cond_concat = cond_concat[:, 0].contiguous()
         if orig is None or mask is None:
             orig, mask = torch.zeros(shape, device=dev), torch.zeros(shape, device=dev)
         else:
@@ -391,7 +400,7 @@ def make_sampler(model, args, seed: int, sample_offset: int = 0):
     return SDFSampler(model.ldm, seed=seed, sample_offset=sample_offset, graph=getattr(args, "hip_graph", False)), None
 
 
-def generate_songs(model, params, args, cond, cond_mid, orig, mask, seed: int, rank: int = 0, world: int = 1):
+def generate_songs(model, params, args, cond, cond_mid, orig, mask, seed: int, rank: int = 0, world: int = 1, cond_concat=None):
     """This rank's share of ``args.num_generate`` independent generations of the same conditions.
 
     The reference loops over the songs (``inference_sdf.py:774``); here they are ONE batch and the unit of multi-GPU
@@ -410,10 +419,12 @@ def generate_songs(model, params, args, cond, cond_mid, orig, mask, seed: int, r
     if n_local == 0:
         gen = torch.empty(0, 2 * B if args.autoreg else B, C, H // 2 if args.autoreg else H, W, device=cond.device)
     elif args.autoreg:
-        gen = expmt.predict_songs(rep(cond), rep(cond_mid), args.uncond_scale, orig=rep(orig), mask=rep(mask))   # [n,2B,C,H/2,W]
+        gen = expmt.predict_songs(rep(cond), rep(cond_mid), args.uncond_scale, orig=rep(orig), mask=rep(mask),
+                                  cond_concat=rep(cond_concat))   # [n,2B,C,H/2,W]
     else:
         flat = lambda v: None if v is None else rep(v).reshape(n_local * B, *v.shape[1:])
-        gen = expmt.predict(flat(cond), None, args.uncond_scale, False, flat(orig), flat(mask)).reshape(n_local, B, C, H, W)
+        gen = expmt.predict(flat(cond), None, args.uncond_scale, False, flat(orig), flat(mask),
+                            cond_concat=flat(cond_concat)).reshape(n_local, B, C, H, W)
     return gen, expmt
 
 
@@ -494,14 +505,19 @@ def main(argv=None):
         bars = [int(v) for v in args.bar_list.split(",")] if args.bar_list else None
         mask = get_mask(orig, args.inpaint_type, bars).to(orig.device)
 
+    cond_concat = None
     if params.get("concat_blurry", False):
-        # inference_sdf.py:797-803 - the denoiser of this variant takes cat([x, blurry image], 1); the generation entry points of
-        # Experiments accept cond_concat, the batched multi-song driver below does not carry it
-        raise SystemExit("params.concat_blurry: use Experiments.generate/inpaint(cond_concat=get_blurry_image(prmat2c, params.concat_ratio)); "
-                         "the reference's own training path for this variant ends in exit(0) (models/model_sdf.py:227-229)")
+        # inference_sdf.py:797-803 - the denoiser of this variant takes cat([x, blurry image], 1)
+        if prmat2c_inp is None:
+            raise SystemExit("params.concat_blurry needs the image to blur: prmat2c in --cond_npz (or a --from_song_npz song)")
+        cond_concat = get_blurry_image(prmat2c_inp[:cond.shape[0]], params.get("concat_ratio", 1 / 8))
+        n = min(cond.shape[0], cond_concat.shape[0])
+        cond, cond_concat = cond[:n], cond_concat[:n]
+        cond_mid = None if cond_mid is None else cond_mid[:n]
+        orig, mask = (None if v is None else v[:n] for v in (orig, mask))
     S, B = args.num_generate, cond.shape[0]
     say(f"generating {S} song(s) x {B} segment(s) with uncond_scale = {args.uncond_scale} on {world} GPU(s)")
-    gen, expmt = generate_songs(model, params, args, cond, cond_mid, orig, mask, seed, rank, world)
+    gen, expmt = generate_songs(model, params, args, cond, cond_mid, orig, mask, seed, rank, world, cond_concat=cond_concat)
     gen = pfdist.gather_rows(gen, S, rank, world)   # [S, ...] on every rank (131 KB per image; the only end-of-run exchange)
     if rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)

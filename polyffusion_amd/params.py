@@ -37,6 +37,9 @@ PRESETS: Dict[str, Dict[str, Any]] = {
     "sdf_txt": dict(_UNET, model_name="sdf_txt", d_cond=1024, cond_type="txt", **_TXT),
     "sdf_chd8bar_txt": dict(_UNET, model_name="sdf_chd8bar_txt", d_cond=1536, cond_type="chord+txt", **_CHD, **_TXT),
     "sdf_txtvnl": dict(_UNET, model_name="sdf_txtvnl", d_cond=128, cond_type="txt", use_enc=False),
+    # params/sdf_concat.yaml as shipped (in_channels 3: with a 2-channel blurry image the reference's own cat([x, cond_concat]) does not fit it either)
+    "sdf_concat": dict(_UNET, model_name="sdf_concat", in_channels=3, d_cond=1152, cond_type="chord", cond_mode="uncond", use_enc=False,
+                       chd_n_step=32, chd_input_dim=36, concat_blurry=True, concat_ratio=0.25),
     "sdf_chdvnl": dict(_UNET, model_name="sdf_chdvnl", d_cond=1152, cond_type="chord", use_enc=False,
                        chd_n_step=32, chd_input_dim=36),
 }

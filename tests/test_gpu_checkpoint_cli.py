@@ -184,3 +184,35 @@ def test_cli_hip_graph_gives_the_same_files(tmp_path):
         assert inference_sdf.main(argv) == 0
         outs.append(np.load(out / sorted(f for f in os.listdir(out) if f.endswith(".npy"))[0]))
     assert outs[0].shape == (4, 2, 64, 128) and np.array_equal(outs[0], outs[1])
+
+
+def test_cli_concat_blurry_params(tmp_path):
+    """params.concat_blurry (ref:inference_sdf.py:797-803): the CLI blurs the given prmat2c and carries it as cond_concat through the
+    batched multi-song driver; the result is what Experiments.predict(cond_concat=...) gives for the same seed."""
+    from polyffusion_amd.sampler import SDFSampler
+    params = dict(PARAMS, model_name="small_concat", in_channels=4, concat_blurry=True, concat_ratio=0.25)
+    (tmp_path / "params.yaml").write_text(yaml.safe_dump(params))
+    n = 2
+    img = synth.prmat2c_image(31, n, 128)
+    np.savez(tmp_path / "cond.npz", chord=synth.chords(n, 32), prmat2c=img)
+    out = tmp_path / "out"
+    argv = ["--custom_params_path", str(tmp_path / "params.yaml"), "--synthetic_weights", "--cond_npz", str(tmp_path / "cond.npz"),
+            "--ddim", "--ddim_steps", "4", "--uncond_scale", "2.0", "--seed", "5", "--num_generate", "2", "--output_dir", str(out)]
+    assert inference_sdf.main(argv) == 0
+    npys = sorted(f for f in os.listdir(out) if f.endswith(".npy"))
+    assert len(npys) == 2
+    a = np.load(out / npys[0])
+    assert a.shape == (n, 2, 128, 128) and np.isfinite(a).all()
+    # the same thing by hand
+    args = inference_sdf.make_parser().parse_args(argv)
+    p = inference_sdf.load_params(str(tmp_path / "params.yaml"))
+    model = inference_sdf.load_model(p, args)
+    cond = model._encode_chord(torch.from_numpy(synth.chords(n, 32)).cuda())
+    cc = inference_sdf.get_blurry_image(torch.from_numpy(img).cuda(), 0.25)
+    gen, _ = inference_sdf.generate_songs(model, p, args, cond, None, None, None, 5, cond_concat=cc)
+    assert np.array_equal(gen[0].cpu().numpy(), a)
+    # without the image to blur the CLI says so; with the shipped sdf_concat preset (in_channels 3) the 2-channel blurry image does not fit
+    # the denoiser - in the reference (cat + conv shape error) as here
+    np.savez(tmp_path / "cond2.npz", chord=synth.chords(n, 32))
+    with pytest.raises(SystemExit, match="needs the image to blur"):
+        inference_sdf.main(argv[:4] + [str(tmp_path / "cond2.npz")] + argv[5:])

@@ -167,3 +167,90 @@ def test_other_shipped_param_sets_full_size(name, d_cond):
     err = (eps.cpu() - ref).abs().max().item()
     print(f"{name} eps max-abs-diff vs oracle:", err)
     assert err < TOL_EPS
+
+
+def _tape(seed, n, shape):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return [rng.standard_normal(shape).astype(np.float32) for _ in range(n)]
+
+
+class _Tape:
+    def __init__(self, arrs):
+        self.arrs, self.i = arrs, 0
+
+    def __call__(self, shape):
+        a = torch.from_numpy(self.arrs[self.i]); self.i += 1
+        assert tuple(a.shape) == tuple(shape)
+        return a
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_config1_ddpm_uncond_batch1_10_steps_vs_reference(golden, precision):
+    """BASELINE.json configs[0] on the GPU: DDPM, uncond_scale = 0 (the denoiser only ever sees the all(-1) condition), batch 1, 10 reverse
+    steps, FULL model size - against the image the REAL reference produced on the CPU from the same seeded noise tape
+    (tests/golden/config1_full.npz, tools/make_goldens_config1.py)."""
+    g = golden("config1_full.npz")
+    draws = _tape(int(g["seed"]), int(g["n_draws"]), (1, 2, 128, 128))
+    assert abs(float(draws[0].sum()) - float(g["first_draw_sum"])) < 1e-3      # the regenerated tape is the recorded one
+    p = preset("sdf_chd8bar")
+    m = synthetic_model(p)
+    m.ldm.eps_model.set_precision(precision)
+    tape = _Tape(draws[1:])
+    ex = Experiments("sdf_chd8bar", dict(p, n_steps=10), SDFSampler(m.ldm, noise_fn=tape))
+    assert ex.t_idx == 9
+    out = ex.predict(torch.zeros(1, 1, 512).cuda(), uncond_scale=0.0, noise=torch.from_numpy(draws[0]).cuda())
+    assert tape.i == len(draws) - 1
+    err = np.abs(out.cpu().numpy() - g["out"]).max()
+    print(f"config 1 (B=1, 10 DDPM steps, uncond) [{precision}] max-abs-diff vs the reference:", err)
+    assert err < TOL_TRAJ
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_repaint_n2_full_size(chd8bar, precision):
+    """RePaint with n = 2 resampling rounds per step (sampler_sdf.py:310-345, incl. the beta-not-sqrt(beta) re-noise of :337-341) at
+    full model size, B = 2, 2 steps, inpainting mask + CFG 2: product vs the oracle on the same noise tape."""
+    chd8bar.ldm.eps_model.set_precision(precision)
+    try:
+        B, T = 2, 1
+        cond = chd8bar._encode_chord(torch.from_numpy(synth.chords(B, 501)).cuda())
+        uc = -torch.ones(B, 1, 512).cuda()
+        x = torch.from_numpy(synth.gaussian((B, 2, 128, 128), 502))
+        orig = torch.from_numpy(synth.prmat2c_image(503, B, 128))
+        mask = torch.zeros(B, 2, 128, 128); mask[:, :, :64] = 1
+        draws = _tape(504, 16, (B, 2, 128, 128))
+        t1, t2 = _Tape(draws), _Tape(draws)
+        got = SDFSampler(chd8bar.ldm, noise_fn=t1).paint(x.cuda(), cond, T, orig=orig.cuda(), mask=mask.cuda(), uncond_scale=2.0,
+                                                         uncond_cond=uc, repaint_n=2)
+        ref_s = sampler_ref.SDFSamplerRef(oracle_model(UNetConfig(d_cond=512)), 1000, *LIN, noise_fn=t2)
+        with torch.no_grad():
+            ref = ref_s.paint(x, cond.cpu(), T, orig=orig, mask=mask, uncond_scale=2.0, uncond_cond=uc.cpu(), repaint_n=2)
+        assert t1.i == t2.i and t1.i > 4
+        err = (got.cpu() - ref).abs().max().item()
+        print(f"RePaint n=2 full size [{precision}] max-abs-diff vs oracle:", err)
+        assert err < TOL_TRAJ
+    finally:
+        chd8bar.ldm.eps_model.set_precision("bf16x3")
+
+
+@pytest.mark.parametrize("disc,eta", [("quad", 0.0), ("uniform", 1.0), ("quad", 1.0)])
+def test_ddim_quad_and_eta_full_size(chd8bar, disc, eta):
+    """DDIM with the 'quad' discretisation and / or eta = 1 (sampler_ddim.py:63-73, 88-99: sigma > 0 draws noise every step) at full
+    model size: three steps from tau index 2, B = 2, inpainting (q_sample re-noising of the known region with orig_noise)."""
+    B = 2
+    cond = chd8bar._encode_chord(torch.from_numpy(synth.chords(B, 601)).cuda())
+    x = torch.from_numpy(synth.gaussian((B, 2, 128, 128), 602))
+    orig = torch.from_numpy(synth.prmat2c_image(603, B, 128))
+    on = torch.from_numpy(synth.gaussian((B, 2, 128, 128), 604))
+    mask = torch.zeros(B, 2, 128, 128); mask[:, :, 96:] = 1
+    draws = _tape(605, 8, (B, 2, 128, 128))
+    t1, t2 = _Tape(draws), _Tape(draws)
+    d = DDIMSampler(chd8bar.ldm, 20, disc, eta, noise_fn=t1)
+    r = sampler_ref.DDIMSamplerRef(oracle_model(UNetConfig(d_cond=512)), 1000, *LIN, n_steps=20, discretize=disc, eta=eta, noise_fn=t2)
+    assert np.array_equal(np.asarray(d.time_steps), r.time_steps)
+    got = d.paint(x.cuda(), cond, 2, orig=orig.cuda(), mask=mask.cuda(), orig_noise=on.cuda())
+    with torch.no_grad():
+        ref = r.paint(x, cond.cpu(), 2, orig=orig, mask=mask, orig_noise=on)
+    assert t1.i == t2.i == (3 if eta > 0 else 0)
+    err = (got.cpu() - ref).abs().max().item()
+    print(f"DDIM {disc} eta={eta} full size max-abs-diff vs oracle:", err)
+    assert err < TOL_TRAJ

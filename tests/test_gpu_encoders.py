@@ -48,3 +48,23 @@ def test_vanilla_conditions_pass_through():
     assert m._encode_chord(ch).shape == (2, 1, 32 * 36)
     pr = torch.from_numpy(synth.prmat(2, 1))
     assert m._encode_txt(pr) is pr
+
+
+@pytest.mark.parametrize("B", [16, 32, 128])
+def test_encoders_at_the_batch_sizes_of_the_configs(B):
+    """Config 2 encodes 16 chord sequences per GPU, config 3 thirty-two, config 4 shards 128 texture images (16 per GPU; a single-GPU
+    run of the same job encodes all 128 at once: 512 two-bar GRU rows).  Oracle on every row."""
+    wc_np, wt_np = synth_chord_encoder_state(7), synth_texture_encoder_state(7)
+    ce = ChordEncoder(36, 512, 512).load_state_dict(wc_np)
+    te = TextureEncoder(256, 1024, 256, 10).load_state_dict(wt_np)
+    wc, wt = unet_ref.to_torch(wc_np), unet_ref.to_torch(wt_np)
+    m = Polyffusion_SDF(None, "chord+txt", chord_enc=ce, txt_enc=te)
+    ch = torch.from_numpy(synth.chords(B, 700 + B))
+    zc = m._encode_chord(ch.cuda())
+    assert zc.shape == (B, 1, 512)
+    assert (zc[:, 0].cpu() - encoders_ref.chord_encoder_mean(wc, ch)).abs().max() < 1e-4
+    pr = torch.from_numpy(synth.prmat(B, 800 + B))
+    zt = m._encode_txt(pr.cuda())
+    assert zt.shape == (B, 1, 1024)
+    assert (zt.cpu() - encoders_ref.encode_txt(wt, pr)).abs().max() < 1e-4
+    assert torch.equal(zt, m._encode_txt(pr.cuda()))          # bit-reproducible

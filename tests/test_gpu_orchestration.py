@@ -131,3 +131,69 @@ def test_predict_songs_on_device_noise_is_shard_invariant(ldm):
     halves = torch.cat([run(0, 2), run(2, 4)])
     assert torch.equal(halves, torch.cat([run(0, 2), run(2, 4)]))      # bit-reproducible
     assert (halves - full).abs().max() < 1e-4 and full.std() > 0
+
+
+# ---- the concat_blurry variant (ref:inference_sdf.py:797-803, sampler_sdf.py:108-118): cond_concat through predict / predict_songs ----
+SMALL4 = UNetConfig(in_channels=4, out_channels=2, channels=32, n_res_blocks=1, attention_levels=(1,),
+                    channel_multipliers=(1, 2), n_heads=2, tf_layers=1, d_cond=32)
+CONCAT_CASES = {
+    "plain": ("ddpm", dict(), False, 3),
+    "inp_cfg": ("ddpm", dict(uncond_scale=2.0), True, 3),
+    "autoreg1": ("ddpm", dict(autoreg=True), False, 1),
+    "ddim": ("ddim", dict(uncond_scale=3.0), True, 3),
+}
+
+
+@pytest.fixture(scope="module", params=["f32", "bf16x3"])
+def ldm4(request):
+    _lib.require_gpu()
+    m = UNetModel(in_channels=4, out_channels=2, channels=32, n_res_blocks=1, attention_levels=(1,),
+                  channel_multipliers=(1, 2), n_heads=2, tf_layers=1, d_cond=32, img_h=16, img_w=16)
+    m.load_state_dict(synth_unet_state(SMALL4, 0))
+    m.set_precision(request.param)
+    return LatentDiffusion(m, None, 0.18215, 1000, *LIN)
+
+
+@pytest.mark.parametrize("tag", list(CONCAT_CASES))
+def test_predict_with_cond_concat_vs_reference_golden(ldm4, golden, tag):
+    from polyffusion_amd.inference_sdf import get_blurry_image
+    g = golden("orchestration_concat.npz")
+    kind, kw, inpaint, n = CONCAT_CASES[tag]
+    tape = Tape(g[f"{tag}_tape"])
+    if kind == "ddpm":
+        ex = Experiments("small", PARAMS, SDFSampler(ldm4, noise_fn=tape))
+    else:
+        ex = Experiments("small", PARAMS, DDIMSampler(ldm4, 10, "uniform", 0.0, noise_fn=tape), t_idx=2)
+    cc = get_blurry_image(torch.from_numpy(g["image"]).cuda(), 0.25)
+    orig = mask = None
+    if inpaint:
+        orig, mask = torch.from_numpy(g["orig"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+    out = ex.predict(torch.from_numpy(g["cond"])[:n].cuda(), torch.from_numpy(g["cond_mid"])[:n].cuda(), orig=orig, mask=mask,
+                     cond_concat=cc[:n], noise=torch.from_numpy(g[f"{tag}_tape0"]).cuda(), **kw)
+    want = g[f"{tag}_out"]
+    assert tuple(out.shape) == want.shape and np.abs(out.cpu().numpy() - want).max() < 1e-3
+    assert tape.i == len(g[f"{tag}_tape"])
+
+
+def test_predict_songs_carries_cond_concat(ldm4, golden):
+    """The batched multi-song driver with cond_concat: S one-segment songs equal S independent predict(autoreg=True) runs; a multi-segment
+    song is refused with torch.cat's message, which is what the reference's own predict raises (fixture: autoreg3_fails)."""
+    from polyffusion_amd.inference_sdf import get_blurry_image
+    g = golden("orchestration_concat.npz")
+    S, T = 3, 3
+    rng = np.random.Generator(np.random.PCG64(21))
+    cond = torch.from_numpy(g["cond"]).cuda().unsqueeze(1)             # [S, 1, 1, 32]
+    cond_mid = torch.from_numpy(g["cond_mid"]).cuda().unsqueeze(1)
+    cc = get_blurry_image(torch.from_numpy(g["image"]).cuda(), 0.25).unsqueeze(1)   # [S, 1, 2, 16, 16]
+    noise = torch.from_numpy(rng.standard_normal((S, 1, 2, 16, 16)).astype(np.float32)).cuda()
+    draws = rng.standard_normal((T * 2, S, 2, 16, 16)).astype(np.float32)
+    ex = Experiments("small", PARAMS, SDFSampler(ldm4, noise_fn=Tape(draws)), t_idx=T)
+    got = ex.predict_songs(cond, cond_mid, uncond_scale=2.0, cond_concat=cc, noise=noise)
+    assert got.shape == (S, 2, 2, 8, 16)
+    for s in range(S):
+        ex1 = Experiments("small", PARAMS, SDFSampler(ldm4, noise_fn=Tape(draws[:, s:s + 1])), t_idx=T)
+        one = ex1.predict(cond[s], cond_mid[s], uncond_scale=2.0, autoreg=True, cond_concat=cc[s], noise=noise[s])
+        assert (got[s] - one).abs().max() < 1e-4, s
+    assert int(g["autoreg3_fails"]) == 1
+    with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
+        ex.predict_songs(cond.transpose(0, 1).contiguous(), cond_mid.transpose(0, 1).contiguous(), cond_concat=cc.transpose(0, 1).contiguous())

@@ -149,3 +149,25 @@ def test_autoreg_data():
     m = sampler_ref.get_autoreg_data(a, 1)
     assert torch.equal(m[0], torch.cat([a[0, 2:], a[1, :2]]))
     assert torch.equal(m[2], torch.cat([a[2, 2:], a[0, :2]]))
+
+
+def test_oracle_config1_full_size_vs_reference(golden):
+    """BASELINE.json configs[0] at FULL model size: the oracle's sampler loop + UNet restatement against the image the real reference
+    produced (tests/golden/config1_full.npz: DDPM, uncond_scale 0, B = 1, 10 reverse steps, seeded noise tape)."""
+    import numpy as np
+    import torch
+    from oracle import sampler_ref, unet_ref
+    from polyffusion_amd.arch import UNetConfig
+    from polyffusion_amd.weights import synth_unet_state
+    g = golden("config1_full.npz")
+    rng = np.random.Generator(np.random.PCG64(int(g["seed"])))
+    draws = [rng.standard_normal((1, 2, 128, 128)).astype(np.float32) for _ in range(int(g["n_draws"]))]
+    cfg = UNetConfig(d_cond=512)
+    w = unet_ref.to_torch(synth_unet_state(cfg, 0))
+    it = iter(draws[1:])
+    s = sampler_ref.SDFSamplerRef(lambda x, t, c: unet_ref.unet_forward(w, cfg, x, t, c), 1000, 0.00085, 0.012,
+                                  noise_fn=lambda shape: torch.from_numpy(next(it)).reshape(shape))
+    with torch.no_grad():
+        out = sampler_ref.predict(s, torch.zeros(1, 1, 512), 512, [1, 2, 128, 128], 9, torch.from_numpy(draws[0]), uncond_scale=0.0)
+    assert next(it, None) is None
+    assert float((out - torch.from_numpy(g["out"])).abs().max()) <= 2e-5

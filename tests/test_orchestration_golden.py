@@ -92,3 +92,40 @@ def test_get_blurry_image(golden):
     for tag, ratio in (("r8", 1 / 8), ("r4", 0.25)):
         got = get_blurry_image(img.clone(), ratio)
         assert got.shape == g[f"blurry_{tag}"].shape and float((got - torch.from_numpy(g[f"blurry_{tag}"])).abs().max()) <= 1e-6
+
+
+SMALL4 = UNetConfig(in_channels=4, out_channels=2, channels=32, n_res_blocks=1, attention_levels=(1,),
+                    channel_multipliers=(1, 2), n_heads=2, tf_layers=1, d_cond=32)
+# tests/golden/orchestration_concat.npz (tools/make_goldens_concat.py): the reference's predict(cond_concat=...) - the concat_blurry variant
+CONCAT_CASES = {
+    "plain": ("ddpm", dict(), False, 3),
+    "inp_cfg": ("ddpm", dict(uncond_scale=2.0), True, 3),
+    "autoreg1": ("ddpm", dict(autoreg=True), False, 1),
+    "ddim": ("ddim", dict(uncond_scale=3.0), True, 3),
+}
+
+
+@pytest.mark.parametrize("tag", list(CONCAT_CASES))
+def test_oracle_predict_with_cond_concat_matches_reference(golden, tag):
+    from polyffusion_amd.inference_sdf import get_blurry_image
+    g = golden("orchestration_concat.npz")
+    kind, kw, inpaint, n = CONCAT_CASES[tag]
+    w = unet_ref.to_torch(synth_unet_state(SMALL4, 0))
+    model = lambda x, t, c: unet_ref.unet_forward(w, SMALL4, x, t, c)
+    draws = iter(g[f"{tag}_tape"])
+    noise_fn = lambda shape: torch.from_numpy(np.ascontiguousarray(next(draws))).reshape(shape)
+    if kind == "ddpm":
+        s, t_idx = sampler_ref.SDFSamplerRef(model, 1000, *LIN, noise_fn=noise_fn), 3
+    else:
+        s, t_idx = sampler_ref.DDIMSamplerRef(model, 1000, *LIN, n_steps=10, noise_fn=noise_fn), 2
+    cc = get_blurry_image(torch.from_numpy(g["image"]), 0.25)          # the product's input preparation, pinned by the same fixture
+    assert float((cc - torch.from_numpy(g["cond_concat"])).abs().max()) <= 1e-6
+    orig = mask = None
+    if inpaint:
+        orig, mask = torch.from_numpy(g["orig"].copy()), torch.from_numpy(g["mask"].copy())
+    with torch.no_grad():
+        out = sampler_ref.predict(s, torch.from_numpy(g["cond"])[:n], SMALL4.d_cond, [n, 2, 16, 16], t_idx, torch.from_numpy(g[f"{tag}_tape0"].copy()),
+                                  cond_mid=torch.from_numpy(g["cond_mid"])[:n], orig=orig, mask=mask, cond_concat=cc[:n], **kw)
+    want = g[f"{tag}_out"]
+    assert out.shape == want.shape and float((out - torch.from_numpy(want)).abs().max()) <= 2e-5
+    assert int(g["autoreg3_fails"]) == 1    # the reference itself cannot run cond_concat autoregressively on a multi-segment batch
