@@ -298,9 +298,9 @@ def make_parser() -> ArgumentParser:
     p.add_argument("--seed", type=int, help="use a specific seed for inference")
     p.add_argument("--autoreg", action="store_true", help="autoregressively inpaint the music segments")
     p.add_argument("--from_dataset", default=None, help="(not rebuilt) choose condition from a dataset")
-    p.add_argument("--from_midi", help="(not rebuilt) choose condition from a midi file")
-    p.add_argument("--from_midi2", help="(not rebuilt)")
-    p.add_argument("--inpaint_from_midi", help="(not rebuilt)")
+    p.add_argument("--from_midi", help="choose condition from a midi file")
+    p.add_argument("--from_midi2", help="choose condition from the 2nd midi file. Used for chord+txt conditioning")
+    p.add_argument("--inpaint_from_midi", help="inpaint a midi file")
     p.add_argument("--inpaint_from_dataset", default=None, help="(not rebuilt)")
     p.add_argument("--inpaint_pop909_use_track", help="(not rebuilt)")
     p.add_argument("--inpaint_type", help="inpaint a song, type: {remaining, below, above, bars}")
@@ -431,9 +431,10 @@ def generate_songs(model, params, args, cond, cond_mid, orig, mask, seed: int, r
 def main(argv=None):
     from . import dist as pfdist
     args = make_parser().parse_args(argv)
-    for flag in ("from_dataset", "from_midi", "from_midi2", "inpaint_from_midi", "inpaint_from_dataset", "inpaint_pop909_use_track"):
+    for flag in ("from_dataset", "inpaint_from_dataset", "inpaint_pop909_use_track"):
         if getattr(args, flag) is not None:
-            raise SystemExit(f"--{flag}: dataset / MIDI front ends are outside the rebuilt hot path; use --cond_npz or --synthetic")
+            raise SystemExit(f"--{flag}: the POP909 / Musicalion validation sets are not part of this build; use --from_midi, "
+                             "--from_song_npz (one song in the same dictionary format), --cond_npz or --synthetic")
     if not torch.cuda.is_available():
         raise SystemExit("inference_sdf needs an AMD GPU (no CPU fallback on this path)")
     rank, world, _ = pfdist.init_from_env()
@@ -470,10 +471,31 @@ def main(argv=None):
 
     length = args.length
     chd = prmat = prmat2c_inp = None
+    def song_from_midi(path, tag):
+        # ref:inference_sdf.py:606-612 - quantise the file, extract its chords (written next to the outputs, as the reference's exp/*.out)
+        from . import midi_to_data
+        data = midi_to_data.get_data_for_single_midi(path, os.path.join(args.output_dir, f"chords_extracted{tag}.out"))
+        if data is None:
+            raise SystemExit(f"{path}: a barline does not fall on the 16th-note grid (get_downbeat_pos_and_filter)")
+        return datasample.DataSample(data).get_whole_song_data()
+
+    inp_from_midi = None
+    if args.inpaint_type is not None and args.inpaint_from_midi is not None:    # :569-575
+        inp_from_midi = song_from_midi(args.inpaint_from_midi, "_inpaint")[0].to(_dev())
+        say(f"Inpainting midi file: {args.inpaint_from_midi}")
     if args.from_song_npz is not None:
         p2c, _, chd, prmat = datasample.DataSample.from_npz(args.from_song_npz).get_whole_song_data()
         chd, prmat, prmat2c_inp = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev())
+    elif args.from_midi is not None and args.uncond_scale != 0.0:
+        p2c, _, chd, prmat = song_from_midi(args.from_midi, "")
+        chd, prmat, prmat2c_inp = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev())
+        say(f"using the {params.cond_type.split('+')[0]} of midi file: {args.from_midi}")
+        if params.cond_type == "chord+txt" and args.from_midi2 is not None:      # texture from a second file (:630-635)
+            prmat = song_from_midi(args.from_midi2, "")[3].to(_dev())
+            say(f"using the txt of midi file: {args.from_midi2}")
     elif args.uncond_scale == 0.0 and args.cond_npz is None and not args.synthetic:
+        if length <= 0 and inp_from_midi is not None:
+            length = inp_from_midi.shape[0]            # :596-597
         if length <= 0:
             raise SystemExit("--length is required for unconditional generation")
         _, _, chd, prmat = dummy_cond_input(length, params)
@@ -487,7 +509,7 @@ def main(argv=None):
         chd = torch.from_numpy(synth.chords(n, seed + 100)).to(_dev())
         prmat = torch.from_numpy(synth.prmat(n, seed + 200)).to(_dev())
     else:
-        raise SystemExit("no condition source: use --from_song_npz, --cond_npz, --synthetic or --uncond_scale 0 --length N")
+        raise SystemExit("no condition source: use --from_midi, --from_song_npz, --cond_npz, --synthetic or --uncond_scale 0 --length N")
 
     cond, cond_mid = encode_conditions(model, params, chd, prmat, args.autoreg)
     if params.cond_mode == "uncond":
@@ -496,9 +518,11 @@ def main(argv=None):
         cond = cond[:length]
         cond_mid = cond_mid[:length] if cond_mid is not None else None
     orig = mask = None
+    if inp_from_midi is not None:
+        prmat2c_inp = inp_from_midi
     if args.inpaint_type is not None:
         if prmat2c_inp is None:
-            raise SystemExit("--inpaint_type needs prmat2c in --cond_npz (or a --from_song_npz song)")
+            raise SystemExit("--inpaint_type needs the image to inpaint: --inpaint_from_midi, prmat2c in --cond_npz, or a --from_midi / --from_song_npz song")
         n = min(cond.shape[0], prmat2c_inp.shape[0])
         cond, orig = cond[:n], prmat2c_inp[:n]
         cond_mid = None if cond_mid is None else cond_mid[:n]

@@ -216,3 +216,32 @@ def test_cli_concat_blurry_params(tmp_path):
     np.savez(tmp_path / "cond2.npz", chord=synth.chords(n, 32))
     with pytest.raises(SystemExit, match="needs the image to blur"):
         inference_sdf.main(argv[:4] + [str(tmp_path / "cond2.npz")] + argv[5:])
+
+
+def test_cli_from_midi_and_inpaint_from_midi(tmp_path):
+    """--from_midi / --inpaint_from_midi (ref:inference_sdf.py:569-575, 606-612): the reference's own example song is quantised, its chords
+    extracted (label file written next to the outputs), its 8-bar segments condition the denoiser and supply the image to inpaint."""
+    run = run_dir(tmp_path, "pt")
+    song = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chord_example.mid")
+    out = tmp_path / "out"
+    argv = ["--chkpt_path", str(run / "chkpts" / "weights_best.pt"), "--from_midi", song, "--length", "3", "--ddim", "--ddim_steps", "4",
+            "--uncond_scale", "2.0", "--seed", "3", "--output_dir", str(out)]
+    assert inference_sdf.main(argv) == 0
+    labels = open(out / "chords_extracted.out").read()
+    assert labels == open(os.path.join(os.path.dirname(song), "chord_example.out")).read()       # the reference's expected labels for this file
+    a = np.load(out / sorted(f for f in os.listdir(out) if f.endswith(".npy"))[0])
+    assert a.shape == (3, 2, 128, 128) and np.isfinite(a).all()
+    out2 = tmp_path / "out2"
+    argv2 = ["--chkpt_path", str(run / "chkpts" / "weights_best.pt"), "--uncond_scale", "0", "--inpaint_type", "below", "--inpaint_from_midi", song,
+             "--ddim", "--ddim_steps", "4", "--seed", "3", "--output_dir", str(out2)]
+    assert inference_sdf.main(argv2) == 0
+    b = np.load(out2 / sorted(f for f in os.listdir(out2) if f.endswith(".npy"))[0])
+    assert b.shape == (12, 2, 128, 128) and os.path.exists(out2 / "chords_extracted_inpaint.out")       # the whole song: 12 segments
+    # the kept region ("below") follows the song's own notes up to the last step's re-noising (q_sample at tau_0, as in the reference)
+    from polyffusion_amd import datasample, midi_to_data
+    p2c = datasample.DataSample(midi_to_data.get_data_for_single_midi(song)).get_whole_song_data()[0].numpy()
+    mask = inference_sdf.get_mask(torch.from_numpy(p2c), "below").numpy()
+    kept = np.abs((b - p2c) * mask)
+    # (sigma of that re-noising: sqrt(1 - alpha_bar[1]) = 0.041)
+    assert kept.max() < 0.25 and kept.sum() / mask.sum() < 0.05 and mask.mean() > 0.1
+    assert (np.abs(b - p2c) * (1 - mask)).sum() / (1 - mask).sum() > 2 * kept.sum() / mask.sum()      # the generated part is free
