@@ -144,10 +144,12 @@ int pf_comm_destroy(pf_comm* comm);
  * Rounding is the reference's int(round(v)) > 0 (== v > 0.5); custom_round != 0 selects utils.py:395-399 for the onset. */
 int pf_prmat2c_durations(const float* prmat2c, int n, int steps, int custom_round, int32_t* dur, void* stream);
 
-/* ---- condition encoders (replace RnnEncoder.forward dl_modules/chord_enc.py:15-22 and
- *      TextureEncoder.forward dl_modules/txt_enc.py:23-35; only the Normal's mean is produced) */
+/* ---- condition encoders (replace RnnEncoder.forward dl_modules/chord_enc.py:15-22, TextureEncoder.forward
+ *      dl_modules/txt_enc.py:23-35 and PianoTreeEncoder.forward dl_modules/pianotree_enc.py:97-121; only the Normal's mean is produced)
+ *      PF_ENC_PNOTREE: input_dim = pitch classes + 5 duration digits (135), emb_size = note embedding (128), num_channel = hidden size
+ *      of the per-step note GRU (256), hidden_dim = hidden size of the GRU over the 32 steps (512), z_dim 512 */
 typedef struct pf_encoder pf_encoder;
-enum { PF_ENC_CHORD = 0, PF_ENC_TEXTURE = 1 };
+enum { PF_ENC_CHORD = 0, PF_ENC_TEXTURE = 1, PF_ENC_PNOTREE = 2 };
 int pf_encoder_create(int kind, int input_dim, int emb_size, int hidden_dim, int z_dim, int num_channel, pf_encoder** out);
 void pf_encoder_destroy(pf_encoder* e);
 size_t pf_encoder_weight_bytes(const pf_encoder* e);
@@ -155,7 +157,9 @@ int pf_encoder_pack_param(pf_encoder* e, const char* key, const float* src, cons
 int pf_encoder_pack_missing(const pf_encoder* e, char* buf, size_t buf_len);
 int pf_encoder_bind_weights(pf_encoder* e, const void* dev_blob);
 size_t pf_encoder_workspace_bytes(const pf_encoder* e, int batch);
-/* chord:   x [B,T,input_dim] -> mu [B,z_dim];   texture: x [B,32,128] -> mu [B,z_dim] */
+/* chord:   x [B,T,input_dim] -> mu [B,z_dim];   texture: x [B,32,128] -> mu [B,z_dim];
+ * pnotree: x [B,32,n_step,6] - the index grid (pitch index, 5 duration digits) of B two-bar segments with n_step = max_simu_note
+ *          entries per time step, stored as floats - -> mu [B,z_dim] */
 int pf_encoder_forward(pf_encoder* e, const float* x, int batch, int n_step, float* mu,
                        void* workspace, size_t workspace_bytes, void* stream);
 

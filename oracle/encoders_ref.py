@@ -71,3 +71,50 @@ def encode_txt(w: Tensors, prmat: torch.Tensor) -> torch.Tensor:
     """models/model_sdf.py:153-164 - four 2-bar segments, means concatenated -> [B,1,1024]."""
     zs = [texture_encoder_mean(w, seg) for seg in prmat.split(32, 1)]
     return torch.cat(zs, dim=-1).unsqueeze(1)
+
+
+def gru_direction_packed(x: torch.Tensor, lengths: torch.Tensor, w_ih, w_hh, b_ih, b_hh, reverse: bool) -> torch.Tensor:
+    """Final hidden state of one GRU direction over variable-length sequences, i.e. what ``nn.GRU`` returns for a
+    ``pack_padded_sequence`` input: sequence b is advanced through its first ``lengths[b]`` elements only (in reverse order for the
+    backward direction)."""
+    N, S, _ = x.shape
+    H = w_hh.shape[1]
+    h = x.new_zeros(N, H)
+    gi_all = F.linear(x, w_ih, b_ih)
+    for step in range(S):
+        live = step < lengths
+        t = torch.where(live, (lengths - 1 - step) if reverse else torch.full_like(lengths, step), torch.zeros_like(lengths))
+        gi = gi_all[torch.arange(N), t]
+        gh = F.linear(h, w_hh, b_hh)
+        i_r, i_z, i_n = gi.chunk(3, dim=-1)
+        h_r, h_z, h_n = gh.chunk(3, dim=-1)
+        r = torch.sigmoid(i_r + h_r)
+        z = torch.sigmoid(i_z + h_z)
+        n = torch.tanh(i_n + r * h_n)
+        h = torch.where(live.unsqueeze(1), (1.0 - z) * n + z * h, h)
+    return h
+
+
+def pianotree_encoder_mean(w: Tensors, grid: torch.Tensor, pitch_pad: int = 130) -> torch.Tensor:
+    """dl_modules/pianotree_enc.py:69-121 on an index grid [B,32,S,6] (int64): lengths = S - pads; multi-hot rows (one-hot pitch
+    over 130 classes - the pad index has no column - + the 5 duration digits as floats, pad digit 2 included); note embedding;
+    bi-GRU over each step's notes (packed); bi-GRU over the 32 steps; ``linear_mu``."""
+    B, T, S, _ = grid.shape
+    P = w["note_embedding.weight"].shape[1] - 5
+    lengths = S - (grid[..., 0] == pitch_pad).sum(-1).reshape(-1)
+    onehot = F.one_hot(grid[..., 0], P + 1)[..., :P].float()
+    x = torch.cat([onehot, grid[..., 1:].float()], dim=-1)
+    emb = F.linear(x, w["note_embedding.weight"], w["note_embedding.bias"]).reshape(B * T, S, -1)
+    g = "enc_notes_gru."
+    hf = gru_direction_packed(emb, lengths, w[g + "weight_ih_l0"], w[g + "weight_hh_l0"], w[g + "bias_ih_l0"], w[g + "bias_hh_l0"], False)
+    hb = gru_direction_packed(emb, lengths, w[g + "weight_ih_l0_reverse"], w[g + "weight_hh_l0_reverse"], w[g + "bias_ih_l0_reverse"],
+                              w[g + "bias_hh_l0_reverse"], True)
+    steps = torch.cat([hf, hb], dim=-1).reshape(B, T, -1)
+    h = bigru_final(w, "enc_time_gru.", steps)
+    return F.linear(h, w["linear_mu.weight"], w["linear_mu.bias"])
+
+
+def encode_pnotree(w: Tensors, pnotree: torch.Tensor) -> torch.Tensor:
+    """models/model_sdf.py:138-151 - four 2-bar segments [B,32,S,6], means concatenated -> [B,1,2048]."""
+    zs = [pianotree_encoder_mean(w, seg) for seg in pnotree.split(32, 1)]
+    return torch.cat(zs, dim=-1).unsqueeze(1)

@@ -219,3 +219,21 @@ def texture_encoder_param_shapes(emb_size=256, hidden_dim=1024, z_dim=256, num_c
     out["linear_var.weight"] = (z_dim, 2 * hidden_dim)
     out["linear_var.bias"] = (z_dim,)
     return out
+
+
+def pianotree_encoder_param_shapes(note_size=135, note_emb_size=128, enc_notes_hid_size=256, enc_time_hid_size=512, z_size=512):
+    """reference: dl_modules/pianotree_enc.py:43-59 (note embedding, bi-GRU over the notes of a step, bi-GRU over the 32 steps, two heads)."""
+    out = OrderedDict()
+    out["note_embedding.weight"] = (note_emb_size, note_size)
+    out["note_embedding.bias"] = (note_emb_size,)
+    for name, hid, inp in (("enc_notes_gru", enc_notes_hid_size, note_emb_size), ("enc_time_gru", enc_time_hid_size, 2 * enc_notes_hid_size)):
+        for sfx in ("", "_reverse"):
+            out[f"{name}.weight_ih_l0{sfx}"] = (3 * hid, inp)
+            out[f"{name}.weight_hh_l0{sfx}"] = (3 * hid, hid)
+            out[f"{name}.bias_ih_l0{sfx}"] = (3 * hid,)
+            out[f"{name}.bias_hh_l0{sfx}"] = (3 * hid,)
+    out["linear_mu.weight"] = (z_size, 2 * enc_time_hid_size)
+    out["linear_mu.bias"] = (z_size,)
+    out["linear_std.weight"] = (z_size, 2 * enc_time_hid_size)
+    out["linear_std.bias"] = (z_size,)
+    return out

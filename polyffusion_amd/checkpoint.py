@@ -156,22 +156,27 @@ def load_checkpoint(path: str) -> Tuple[State, Optional[dict]]:
     raise RuntimeError(f"{path}: unknown checkpoint type (expected .pt or .ckpt)")
 
 
-def split_state(state: Mapping[str, torch.Tensor]):
-    """Full-model state_dict -> (unet, chord_enc, txt_enc) sub-dicts with their prefixes removed.
-    The recomputable schedule buffers and the decode-only modules are dropped; anything else is an error
-    with torch's wording (``unexpected key``)."""
-    unet, ce, te = {}, {}, {}
+def split_state_full(state: Mapping[str, torch.Tensor]) -> Dict[str, State]:
+    """Full-model state_dict -> sub-dicts ``unet`` / ``chord_enc`` / ``txt_enc`` / ``pnotree_enc`` with their prefixes removed.
+    The recomputable schedule buffers and the decode-only modules are dropped; anything else is an error with torch's wording
+    (``unexpected key``)."""
+    out: Dict[str, State] = {"unet": {}, "chord_enc": {}, "txt_enc": {}, "pnotree_enc": {}}
     for k, v in state.items():
         if k.startswith("ldm.eps_model."):
-            unet[k[len("ldm.eps_model."):]] = v
-        elif k.startswith("chord_enc."):
-            ce[k[len("chord_enc."):]] = v
-        elif k.startswith("txt_enc."):
-            te[k[len("txt_enc."):]] = v
+            out["unet"][k[len("ldm.eps_model."):]] = v
+        elif k.split(".")[0] in ("chord_enc", "txt_enc", "pnotree_enc"):
+            part = k.split(".")[0]
+            out[part][k[len(part) + 1:]] = v
         elif k in ("ldm.alpha", "ldm.beta", "ldm.alpha_bar", "ldm.sigma2"):
             continue  # recomputed from the params (latent_diffusion.py:90-103)
-        elif k.split(".")[0] in ("chord_dec", "pnotree_enc", "pnotree_dec"):
+        elif k.split(".")[0] in ("chord_dec", "pnotree_dec"):
             continue  # decode/debug-only modules
         else:
             raise RuntimeError(f"unexpected key in checkpoint: {k}")
-    return unet, ce, te
+    return out
+
+
+def split_state(state: Mapping[str, torch.Tensor]):
+    """(unet, chord_enc, txt_enc) of ``split_state_full`` (the PianoTree encoder of the sdf_pnotree variant: use the full form)."""
+    f = split_state_full(state)
+    return f["unet"], f["chord_enc"], f["txt_enc"]

@@ -97,6 +97,10 @@ int launch_step_end(pf_step_state* st, int draws_used, hipStream_t s);
 
 // encoder kernels
 int launch_gru_gates(const float* gi, int ld_gi, const float* gh, float* h, int ld_h, int batch, int hidden, hipStream_t s);
+int launch_pnotree_embed(const float* grid, const float* w, const float* bias, float* out, int rows, int emb, int pitch_range, hipStream_t s);
+int launch_pnotree_lengths(const float* grid, int* lens, int nseq, int max_simu_note, int pad, hipStream_t s);
+int launch_gru_gates_masked(const float* gi, const float* gh, float* h, int ld_h, int nseq, int hidden, int seq_len, const int* lens,
+                            int step, int reverse, hipStream_t s);
 int launch_txt_frontend(const float* pr, const float* w, const float* bias, float* out, int batch, int num_channel,
                         hipStream_t s);
 

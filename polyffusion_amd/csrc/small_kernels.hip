@@ -573,6 +573,66 @@ int launch_gru_gates(const float* gi, int ld_gi, const float* gh, float* h, int 
   return PF_OK;
 }
 
+// ------------------------------------------------------------------ PianoTree encoder pieces (dl_modules/pianotree_enc.py)
+// grid row = (pitch index, 5 duration digits) as floats; its multi-hot form (one-hot pitch over P classes - the pad index P has no
+// column - followed by the five digits, :78-95) times note_embedding (:43): out[row][j] = b[j] + W[j][pitch] + sum_k d_k W[j][P+k]
+__global__ void pnotree_embed_kernel(const float* __restrict__ grid, const float* __restrict__ w, const float* __restrict__ bias,
+                                     float* __restrict__ out, int rows, int E, int P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * E) return;
+  const int row = i / E, j = i % E;
+  const float* g = grid + (size_t)row * 6;
+  const float* wj = w + (size_t)j * (P + 5);
+  const int pitch = (int)g[0];
+  float acc = bias[j];
+  if (pitch >= 0 && pitch < P) acc += wj[pitch];
+  for (int k = 0; k < 5; ++k) acc = fmaf(g[1 + k], wj[P + k], acc);
+  out[i] = acc;
+}
+// notes sounding at a time step = S minus the pad entries (get_len_index_tensor :69-76)
+__global__ void pnotree_lengths_kernel(const float* __restrict__ grid, int* __restrict__ lens, int nseq, int S, int pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseq) return;
+  int n = S;
+  for (int k = 0; k < S; ++k) n -= ((int)grid[((size_t)i * S + k) * 6] == pad);
+  lens[i] = n;
+}
+// GRU cell update over packed variable-length sequences (pack_padded_sequence, :104-107): sequence b takes part in `step` only while
+// step < lens[b]; its input is element `step` (forward) or lens[b]-1-step (reverse) of gi [N][S][3H]
+__global__ void gru_gates_masked_kernel(const float* __restrict__ gi, const float* __restrict__ gh, float* __restrict__ h, int ld_h,
+                                        int N, int H, int S, const int* __restrict__ lens, int step, int reverse) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * H) return;
+  const int b = i / H, j = i % H;
+  const int len = lens[b];
+  if (step >= len) return;
+  const int t = reverse ? len - 1 - step : step;
+  const float* a = gi + ((size_t)b * S + t) * 3 * H;
+  const float* c = gh + (size_t)b * 3 * H;
+  const float r = 1.0f / (1.0f + expf(-(a[j] + c[j])));
+  const float z = 1.0f / (1.0f + expf(-(a[H + j] + c[H + j])));
+  const float nn = tanhf(a[2 * H + j] + r * c[2 * H + j]);
+  float* hp = h + (size_t)b * ld_h + j;
+  *hp = (1.0f - z) * nn + z * *hp;
+}
+int launch_pnotree_embed(const float* grid, const float* w, const float* bias, float* out, int rows, int emb, int pitch_range, hipStream_t s) {
+  hipLaunchKernelGGL(pnotree_embed_kernel, dim3(cdiv(rows * emb, 256)), dim3(256), 0, s, grid, w, bias, out, rows, emb, pitch_range);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+int launch_pnotree_lengths(const float* grid, int* lens, int nseq, int max_simu_note, int pad, hipStream_t s) {
+  hipLaunchKernelGGL(pnotree_lengths_kernel, dim3(cdiv(nseq, 256)), dim3(256), 0, s, grid, lens, nseq, max_simu_note, pad);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+int launch_gru_gates_masked(const float* gi, const float* gh, float* h, int ld_h, int nseq, int hidden, int seq_len, const int* lens,
+                            int step, int reverse, hipStream_t s) {
+  hipLaunchKernelGGL(gru_gates_masked_kernel, dim3(cdiv(nseq * hidden, 256)), dim3(256), 0, s, gi, gh, h, ld_h, nseq, hidden, seq_len, lens, step,
+                     reverse);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
 // ------------------------------------------------------------------ texture encoder front end
 // pr [B,32,128] -> conv(1->C,(4,12),stride(4,1)) -> ReLU -> maxpool(1,4) -> [B,C,8,29] (contiguous; the
 // reference then reinterprets this buffer as [B,8,C*29] without a permute - txt_enc.py:27).

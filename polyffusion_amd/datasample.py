@@ -10,8 +10,7 @@ names and results, for the ``data`` dictionary ``get_data_for_single_midi`` / th
     db_pos       downbeat positions in bins, db_pos_filter  bool mask of the usable ones
     chord        [beats, 14] int  (root, 12 chroma flags, bass) - one row per beat (4 bins)
 
-A segment is 8 bars = 32 beats = 128 bins.  Host-side integer work (it runs once per generation, before the sampler);
-the piano-tree representation belongs to the pnotree model variants, which are outside the rebuilt path.
+A segment is 8 bars = 32 beats = 128 bins.  Host-side integer work (it runs once per generation, before the sampler).
 """
 from __future__ import annotations
 
@@ -55,8 +54,29 @@ def nmat_to_prmat2c(nmat: np.ndarray, n_step: int = 32) -> np.ndarray:
     return pr
 
 
+def nmat_to_pianotree_repr(nmat: np.ndarray, n_step: int = 32, max_note_count: int = 20, dur_pad_ind: int = 2, min_pitch: int = 0,
+                           pitch_sos_ind: int = 128, pitch_eos_ind: int = 129, pitch_pad_ind: int = 130) -> np.ndarray:
+    """ref:utils.py:132-171 - (onset, pitch, duration) rows -> [n_step, max_note_count, 6] int64: per step a start token, the notes in
+    row order as (pitch, 5 binary digits of duration - 1, durations capped at 32), an end token, padding (pitch 130, digits 2).
+    A step with more than ``max_note_count - 2`` notes keeps overwriting its last slot, like the reference."""
+    out = np.ones((n_step, max_note_count, 6), dtype=np.int64) * dur_pad_ind
+    out[:, :, 0] = pitch_pad_ind
+    out[:, 0, 0] = pitch_sos_ind
+    cur = np.ones(n_step, dtype=np.int64)
+    for o, p, d in nmat:
+        if o >= n_step:
+            continue
+        out[o, cur[o], 0] = p - min_pitch
+        d = min(int(d), 32)
+        out[o, cur[o], 1:] = [int(c) for c in np.binary_repr(d - 1, width=5)]
+        if cur[o] < max_note_count - 1:
+            cur[o] += 1
+    out[np.arange(n_step), cur, 0] = pitch_eos_ind
+    return out
+
+
 class DataSample:
-    """ref:data/datasample.py:29-216 (``__getitem__`` / ``get_whole_song_data``; the pnotree slot is returned as None)."""
+    """ref:data/datasample.py:29-216 (``__getitem__`` / ``get_whole_song_data``)."""
 
     def __init__(self, data) -> None:
         self.notes = np.asarray(data["notes"])
@@ -95,20 +115,21 @@ class DataSample:
         chord = self.chord[db // N_BIN:db // N_BIN + SEG_LGTH]
         if chord.shape[0] < SEG_LGTH:
             chord = np.append(chord, np.zeros([SEG_LGTH - chord.shape[0], 14], dtype=np.int32), axis=0)
-        return nmat_to_prmat2c(nmat, SEG_LGTH_BIN), None, chord, nmat_to_prmat(nmat, SEG_LGTH_BIN)
+        return nmat_to_prmat2c(nmat, SEG_LGTH_BIN), nmat_to_pianotree_repr(nmat, SEG_LGTH_BIN), chord, nmat_to_prmat(nmat, SEG_LGTH_BIN)
 
-    def get_whole_song_data(self) -> Tuple[torch.Tensor, None, torch.Tensor, torch.Tensor]:
+    def get_whole_song_data(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
         """Consecutive non-overlapping 8-bar segments from the first usable downbeat on (ref:data/datasample.py:191-216):
-        ``prmat2c [S, 2, 128, 128]``, None, ``chord [S, 32, 36]`` one-hot, ``prmat [S, 128, 128]`` (float32)."""
-        prmat2c, chord, prmat = [], [], []
+        ``prmat2c [S, 2, 128, 128]``, ``pnotree [S, 128, 20, 6]`` int64, ``chord [S, 32, 36]`` one-hot, ``prmat [S, 128, 128]`` (float32)."""
+        prmat2c, pnotree, chord, prmat = [], [], [], []
         idx = i = 0
         while i < len(self):
-            p2, _, c, pm = self[i]
+            p2, pt, c, pm = self[i]
             prmat2c.append(p2)
+            pnotree.append(pt)
             chord.append(chd_to_onehot(c))
             prmat.append(pm)
             idx += SEG_LGTH_BIN
             while i < len(self) and self.db_pos[i] < idx:
                 i += 1
-        return (torch.from_numpy(np.array(prmat2c, dtype=np.float32)), None,
+        return (torch.from_numpy(np.array(prmat2c, dtype=np.float32)), torch.from_numpy(np.array(pnotree, dtype=np.int64)),
                 torch.from_numpy(np.array(chord, dtype=np.float32)), torch.from_numpy(np.array(prmat, dtype=np.float32)))

@@ -42,7 +42,8 @@ def dummy_cond_input(length, params):
     prmat2c = torch.zeros([length, 2, h, w], device=_dev())
     chord = torch.zeros([length, params.chd_n_step, params.chd_input_dim], device=_dev()) if "chord" in params.cond_type else None
     prmat = torch.zeros([length, h, w], device=_dev())
-    return prmat2c, None, chord, prmat
+    pnotree = torch.zeros([length, h, 20, 6], dtype=torch.int64, device=_dev())     # ref:inference_sdf.py:64
+    return prmat2c, pnotree, chord, prmat
 
 
 def get_blurry_image(img: torch.Tensor, ratio: float = 1 / 8) -> torch.Tensor:
@@ -251,6 +252,12 @@ def build_encoders(params, device=None):
     return chord_enc, txt_enc
 
 
+def build_pnotree_encoder(params, device=None):
+    """The frozen PianoTree encoder of the sdf_pnotree variant (ref:inference_sdf.py:676-680; default sizes, max_simu_note 20)."""
+    from .model_sdf import PianoTreeEncoder
+    return PianoTreeEncoder(max_simu_note=20, device=device) if params.cond_type == "pnotree" else None
+
+
 def synthetic_model(params, seed: int = 0, device=None) -> Polyffusion_SDF:
     """Whole model with deterministic synthetic weights (same generator as the golden vectors)."""
     from .arch import UNetConfig
@@ -263,12 +270,22 @@ def synthetic_model(params, seed: int = 0, device=None) -> Polyffusion_SDF:
     if txt_enc is not None:
         txt_enc.load_state_dict(synth_texture_encoder_state(seed, params.txt_emb_size, params.txt_hidden_dim,
                                                             params.txt_z_dim, params.txt_num_channel))
-    return Polyffusion_SDF(build_ldm(params, unet), params.cond_type, params.cond_mode, chord_enc=chord_enc, txt_enc=txt_enc)
+    pnotree_enc = build_pnotree_encoder(params, device)
+    if pnotree_enc is not None:
+        from .weights import synth_pianotree_encoder_state
+        pnotree_enc.load_state_dict(synth_pianotree_encoder_state(seed))
+    return Polyffusion_SDF(build_ldm(params, unet), params.cond_type, params.cond_mode, chord_enc=chord_enc, txt_enc=txt_enc,
+                           pnotree_enc=pnotree_enc)
 
 
-def encode_conditions(model: Polyffusion_SDF, params, chd, prmat, autoreg: bool):
+def encode_conditions(model: Polyffusion_SDF, params, chd, prmat, autoreg: bool, pnotree=None):
     cond_mid = None
-    if params.cond_type == "chord":
+    if params.cond_type == "pnotree":          # ref:inference_sdf.py:756-760
+        assert pnotree is not None
+        cond = model._encode_pnotree(pnotree)
+        if autoreg:
+            cond_mid = model._encode_pnotree(get_autoreg_data(pnotree))
+    elif params.cond_type == "chord":
         assert chd is not None
         cond = model._encode_chord(chd)
         if autoreg:
@@ -318,7 +335,7 @@ def make_parser() -> ArgumentParser:
     p.add_argument("--params_preset", help="use a built-in params preset instead of a params.yaml (e.g. sdf_chd8bar)")
     p.add_argument("--synthetic_weights", action="store_true", help="deterministic synthetic weights instead of a checkpoint")
     p.add_argument("--synthetic", action="store_true", help="seeded synthetic chords / textures as conditions")
-    p.add_argument("--cond_npz", help="npz with arrays chord [B,32,36] and/or prmat [B,128,128] (and prmat2c for inpainting)")
+    p.add_argument("--cond_npz", help="npz with arrays chord [B,32,36] and/or prmat [B,128,128] and/or pnotree [B,128,20,6] (and prmat2c for inpainting)")
     p.add_argument("--from_song_npz", help="a quantised song in the reference's data-dictionary format (notes, start_table, db_pos, "
                    "db_pos_filter, chord - what get_data_for_single_midi / the POP909 .npz files hold): its 8-bar segments supply the "
                    "chord / texture conditions and the image to inpaint (ref:inference_sdf.py:599-610 via data/datasample.py)")
@@ -330,11 +347,13 @@ def make_parser() -> ArgumentParser:
 
 def _packed_blobs(params, args, parts, chord_enc, txt_enc):
     """Rank 0's half of ``load_model``: checkpoint (or synthetic) state_dicts -> packed host blobs, one per sub-model."""
-    from .checkpoint import load_checkpoint, split_state
+    from .checkpoint import load_checkpoint, split_state_full
     states = {}
     if args.synthetic_weights:
         from .arch import UNetConfig
-        from .weights import synth_chord_encoder_state, synth_texture_encoder_state, synth_unet_state
+        from .weights import synth_chord_encoder_state, synth_pianotree_encoder_state, synth_texture_encoder_state, synth_unet_state
+        if params.cond_type == "pnotree":
+            states["pnotree_enc"] = synth_pianotree_encoder_state(0)
         states["unet"] = synth_unet_state(UNetConfig.from_params(params), 0)
         if chord_enc is not None:
             states["chord_enc"] = synth_chord_encoder_state(0, params.chd_input_dim, params.chd_hidden_dim, params.chd_z_dim)
@@ -347,7 +366,7 @@ def _packed_blobs(params, args, parts, chord_enc, txt_enc):
             path = f"{path}/chkpts/{args.chkpt_name}"
         if not path or not (path.endswith(".pt") or path.endswith(".ckpt")):
             raise SystemExit("--chkpt_path must name a legacy .pt or a Lightning .ckpt checkpoint (or a run directory holding chkpts/)")
-        states["unet"], states["chord_enc"], states["txt_enc"] = split_state(load_checkpoint(path)[0])
+        states = split_state_full(load_checkpoint(path)[0])
     blobs = {}
     for name, mod, _ in parts:
         if not states.get(name):
@@ -368,6 +387,9 @@ def load_model(params, args, rank: int = 0, world: int = 1) -> Polyffusion_SDF:
         parts.append(("chord_enc", chord_enc, int(_lib.load().pf_encoder_weight_bytes(chord_enc._h))))
     if txt_enc is not None:
         parts.append(("txt_enc", txt_enc, int(_lib.load().pf_encoder_weight_bytes(txt_enc._h))))
+    pnotree_enc = build_pnotree_encoder(params)
+    if pnotree_enc is not None:
+        parts.append(("pnotree_enc", pnotree_enc, int(_lib.load().pf_encoder_weight_bytes(pnotree_enc._h))))
     dev = _dev()
     blobs, failure = {}, None
     if rank == 0:
@@ -385,7 +407,8 @@ def load_model(params, args, rank: int = 0, world: int = 1) -> Polyffusion_SDF:
         blob = blobs[name] if rank == 0 else torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
         pfdist.broadcast_blob(blob, 0)
         mod.bind_packed(blob)
-    return Polyffusion_SDF(build_ldm(params, unet), params.cond_type, params.cond_mode, chord_enc=chord_enc, txt_enc=txt_enc)
+    return Polyffusion_SDF(build_ldm(params, unet), params.cond_type, params.cond_mode, chord_enc=chord_enc, txt_enc=txt_enc,
+                           pnotree_enc=pnotree_enc)
 
 
 def make_sampler(model, args, seed: int, sample_offset: int = 0):
@@ -470,7 +493,7 @@ def main(argv=None):
     model = load_model(params, args, rank, world)
 
     length = args.length
-    chd = prmat = prmat2c_inp = None
+    chd = prmat = prmat2c_inp = pnotree = None
     def song_from_midi(path, tag):
         # ref:inference_sdf.py:606-612 - quantise the file, extract its chords (written next to the outputs, as the reference's exp/*.out)
         from . import midi_to_data
@@ -484,11 +507,11 @@ def main(argv=None):
         inp_from_midi = song_from_midi(args.inpaint_from_midi, "_inpaint")[0].to(_dev())
         say(f"Inpainting midi file: {args.inpaint_from_midi}")
     if args.from_song_npz is not None:
-        p2c, _, chd, prmat = datasample.DataSample.from_npz(args.from_song_npz).get_whole_song_data()
-        chd, prmat, prmat2c_inp = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev())
+        p2c, pnotree, chd, prmat = datasample.DataSample.from_npz(args.from_song_npz).get_whole_song_data()
+        chd, prmat, prmat2c_inp, pnotree = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev()), pnotree.to(_dev())
     elif args.from_midi is not None and args.uncond_scale != 0.0:
-        p2c, _, chd, prmat = song_from_midi(args.from_midi, "")
-        chd, prmat, prmat2c_inp = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev())
+        p2c, pnotree, chd, prmat = song_from_midi(args.from_midi, "")
+        chd, prmat, prmat2c_inp, pnotree = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev()), pnotree.to(_dev())
         say(f"using the {params.cond_type.split('+')[0]} of midi file: {args.from_midi}")
         if params.cond_type == "chord+txt" and args.from_midi2 is not None:      # texture from a second file (:630-635)
             prmat = song_from_midi(args.from_midi2, "")[3].to(_dev())
@@ -498,20 +521,25 @@ def main(argv=None):
             length = inp_from_midi.shape[0]            # :596-597
         if length <= 0:
             raise SystemExit("--length is required for unconditional generation")
-        _, _, chd, prmat = dummy_cond_input(length, params)
+        _, pnotree, chd, prmat = dummy_cond_input(length, params)
     elif args.cond_npz is not None:
         z = np.load(args.cond_npz)
         chd = torch.from_numpy(z["chord"]).float().to(_dev()) if "chord" in z else None
         prmat = torch.from_numpy(z["prmat"]).float().to(_dev()) if "prmat" in z else None
         prmat2c_inp = torch.from_numpy(z["prmat2c"]).float().to(_dev()) if "prmat2c" in z else None
+        pnotree = torch.from_numpy(z["pnotree"]).long().to(_dev()) if "pnotree" in z else None
     elif args.synthetic:
         n = length if length > 0 else 1
         chd = torch.from_numpy(synth.chords(n, seed + 100)).to(_dev())
         prmat = torch.from_numpy(synth.prmat(n, seed + 200)).to(_dev())
+        if params.cond_type == "pnotree":
+            pnotree = torch.from_numpy(synth.pnotree(n, seed + 300)).to(_dev())
     else:
         raise SystemExit("no condition source: use --from_midi, --from_song_npz, --cond_npz, --synthetic or --uncond_scale 0 --length N")
 
-    cond, cond_mid = encode_conditions(model, params, chd, prmat, args.autoreg)
+    if params.cond_type == "pnotree" and pnotree is None:
+        raise SystemExit("cond_type pnotree needs the piano-tree grid: --from_midi, --from_song_npz, pnotree in --cond_npz or --synthetic")
+    cond, cond_mid = encode_conditions(model, params, chd, prmat, args.autoreg, pnotree=pnotree)
     if params.cond_mode == "uncond":
         cond = -torch.ones_like(cond)
     if length > 0:

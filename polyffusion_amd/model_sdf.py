@@ -107,6 +107,32 @@ class TextureEncoder(_Encoder):
         return self._run(pr, 8)
 
 
+class PianoTreeEncoder(_Encoder):
+    """``dl_modules/pianotree_enc.py:7-59`` (constructor keywords kept); ``forward`` returns ``(dist, None, lengths)`` so that the
+    reference's ``self.pnotree_enc(seg)[0].mean`` (models/model_sdf.py:144) reads the same."""
+    KIND = 2
+
+    def __init__(self, max_simu_note=20, max_pitch=127, min_pitch=0, pitch_sos=128, pitch_eos=129, pitch_pad=130, dur_pad=2, dur_width=5,
+                 num_step=32, note_emb_size=128, enc_notes_hid_size=256, enc_time_hid_size=512, z_size=512, device=None):
+        if num_step != 32 or max_simu_note > 32:
+            raise ValueError("PianoTreeEncoder: num_step must be 32 and max_simu_note at most 32")
+        self.max_simu_note, self.pitch_pad, self.num_step = max_simu_note, pitch_pad, num_step
+        pitch_range = max_pitch - min_pitch + 3
+        if pitch_pad != pitch_range:
+            raise ValueError("PianoTreeEncoder: pitch_pad must be the index right after the pitch classes (max_pitch - min_pitch + 3)")
+        super().__init__(pitch_range + dur_width, note_emb_size, enc_time_hid_size, z_size, enc_notes_hid_size, device)
+
+    def encode_mean(self, grid: torch.Tensor) -> torch.Tensor:   # [R,32,max_simu_note,6] integer grid -> [R,z]
+        assert tuple(grid.shape[1:]) == (self.num_step, self.max_simu_note, 6), "pianotree grid must be [B,32,max_simu_note,6]"
+        return self._run(grid.to(torch.float32), self.max_simu_note)
+
+    def forward(self, grid):
+        lengths = self.max_simu_note - (grid[:, :, :, 0] == self.pitch_pad).sum(dim=-1)
+        return SimpleNamespace(mean=self.encode_mean(grid)), None, lengths.cpu()
+
+    __call__ = forward
+
+
 def _strip(state, part: str):
     if isinstance(state, (str, bytes)) or hasattr(state, "__fspath__"):   # a checkpoint path, like the reference's fpath argument
         from .checkpoint import load_checkpoint
@@ -130,10 +156,10 @@ class Polyffusion_SDF:
     def __init__(self, ldm: LatentDiffusion, cond_type, cond_mode="cond", chord_enc: Optional[ChordEncoder] = None,
                  chord_dec=None, pnotree_enc=None, pnotree_dec=None, txt_enc: Optional[TextureEncoder] = None,
                  concat_blurry=False, concat_ratio=1 / 8):
-        if pnotree_enc is not None or pnotree_dec is not None or chord_dec is not None:
-            raise NotImplementedError("pnotree / decoder modules are outside the denoising hot path (SURVEY.md 2 #12)")
+        if pnotree_dec is not None or chord_dec is not None:
+            raise NotImplementedError("decoder modules (reconstruction / debugging output) are outside the denoising path (SURVEY.md 2 #12)")
         self.ldm, self.cond_type, self.cond_mode = ldm, cond_type, cond_mode
-        self.chord_enc, self.txt_enc = chord_enc, txt_enc
+        self.chord_enc, self.txt_enc, self.pnotree_enc = chord_enc, txt_enc, pnotree_enc
         self.concat_blurry, self.concat_ratio = concat_blurry, concat_ratio
 
     @classmethod
@@ -148,9 +174,12 @@ class Polyffusion_SDF:
         return model
 
     def load_state_dict(self, state: Mapping[str, object]):
-        from .checkpoint import split_state
+        from .checkpoint import split_state, split_state_full
         unet, ce, te = split_state(state)
         self.ldm.eps_model.load_state_dict(unet)
+        pe = split_state_full(state)["pnotree_enc"]
+        if self.pnotree_enc is not None and pe:
+            self.pnotree_enc.load_state_dict(pe)
         if self.chord_enc is not None and ce:
             self.chord_enc.load_state_dict(ce)
         if self.txt_enc is not None and te:
@@ -164,6 +193,13 @@ class Polyffusion_SDF:
         if self.chord_enc is not None:
             return self.chord_enc(chord).mean.unsqueeze(1)  # [B,1,512]
         return torch.reshape(chord, (-1, 1, chord.shape[1] * chord.shape[2]))
+
+    def _encode_pnotree(self, pnotree: torch.Tensor) -> torch.Tensor:
+        """models/model_sdf.py:138-151: the four 2-bar segments of every sample through the encoder, means concatenated: [B,1,4z]."""
+        assert self.pnotree_enc is not None
+        B, S = pnotree.shape[0], pnotree.shape[2]
+        segs = pnotree.contiguous().view(B * 4, 32, S, 6)      # [B,128,S,6] -> [B*4,32,S,6]: a pure view, rows (b, segment)
+        return self.pnotree_enc(segs)[0].mean.view(B, 1, -1)
 
     def _encode_txt(self, prmat: torch.Tensor) -> torch.Tensor:
         if self.txt_enc is None:

@@ -40,6 +40,7 @@ PRESETS: Dict[str, Dict[str, Any]] = {
     # params/sdf_concat.yaml as shipped (in_channels 3: with a 2-channel blurry image the reference's own cat([x, cond_concat]) does not fit it either)
     "sdf_concat": dict(_UNET, model_name="sdf_concat", in_channels=3, d_cond=1152, cond_type="chord", cond_mode="uncond", use_enc=False,
                        chd_n_step=32, chd_input_dim=36, concat_blurry=True, concat_ratio=0.25),
+    "sdf_pnotree": dict(_UNET, model_name="sdf_pnotree", d_cond=2048, cond_type="pnotree"),
     "sdf_chdvnl": dict(_UNET, model_name="sdf_chdvnl", d_cond=1152, cond_type="chord", use_enc=False,
                        chd_n_step=32, chd_input_dim=36),
 }

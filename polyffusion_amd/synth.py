@@ -70,3 +70,15 @@ def song_data(seed: int, n_bars: int = 20) -> dict:
     chord[:, 1:13] = rng.random((n_bars * 4, 12)) < 0.3
     chord[:, 13] = rng.integers(0, 12, n_bars * 4)
     return {"notes": notes, "start_table": np.array(start_table, dtype=object), "db_pos": db_pos, "db_pos_filter": filt, "chord": chord}
+
+
+def pnotree(n: int, seed: int, n_step: int = 128) -> np.ndarray:
+    """Seeded piano-tree grids [n, n_step, 20, 6] (int64) of sparse random notes - the condition of the sdf_pnotree variant."""
+    from .datasample import nmat_to_pianotree_repr
+    out = []
+    for i in range(n):
+        rng = np.random.Generator(np.random.PCG64([seed, i]))
+        k = int(rng.integers(60, 200))
+        nm = np.stack([rng.integers(0, n_step, k), rng.integers(36, 96, k), rng.integers(1, 17, k)], 1)
+        out.append(nmat_to_pianotree_repr(nm[np.lexsort((nm[:, 2], nm[:, 1], nm[:, 0]))], n_step))
+    return np.stack(out)

@@ -17,6 +17,7 @@ import numpy as np
 from .arch import (
     UNetConfig,
     chord_encoder_param_shapes,
+    pianotree_encoder_param_shapes,
     texture_encoder_param_shapes,
     unet_param_shapes,
 )
@@ -62,4 +63,18 @@ def _synth_rnn(shapes, seed, prefix, hidden_dim):
             out[k] = rng.uniform(-b, b, size=s).astype(np.float32)
         else:
             out[k] = _draw(prefix + k, s, seed)
+    return out
+
+
+def synth_pianotree_encoder_state(seed: int = 0, note_size=135, note_emb_size=128, enc_notes_hid_size=256, enc_time_hid_size=512, z_size=512):
+    """PianoTreeEncoder tensors (dl_modules/pianotree_enc.py); GRU weights at torch's U(-1/sqrt(H), 1/sqrt(H)) scale."""
+    shapes = pianotree_encoder_param_shapes(note_size, note_emb_size, enc_notes_hid_size, enc_time_hid_size, z_size)
+    out = OrderedDict()
+    for k, s in shapes.items():
+        if "_gru." in k:
+            hid = enc_notes_hid_size if k.startswith("enc_notes") else enc_time_hid_size
+            rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(("pnotree_enc." + k).encode())]))
+            out[k] = rng.uniform(-1.0 / hid ** 0.5, 1.0 / hid ** 0.5, size=s).astype(np.float32)
+        else:
+            out[k] = _draw("pnotree_enc." + k, s, seed)
     return out

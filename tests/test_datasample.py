@@ -15,7 +15,7 @@ G = np.load(os.path.join(os.path.dirname(__file__), "golden", "datasample.npz"))
 def test_whole_song_matches_reference(name):
     ds = datasample.DataSample(synth.song_data(int(G[f"{name}_seed"]), int(G[f"{name}_bars"])))
     p2, pn, ch, pm = ds.get_whole_song_data()
-    assert pn is None
+    assert pn.dtype == __import__("torch").int64 and np.array_equal(pn.numpy(), G[f"{name}_pnotree"].astype(np.int64))   # piano-tree grid [S,128,20,6]
     for got, key in ((p2, "prmat2c"), (ch, "chord"), (pm, "prmat")):
         want = G[f"{name}_{key}"]
         assert got.numpy().dtype == want.dtype and np.array_equal(got.numpy(), want), key

@@ -245,3 +245,20 @@ def test_cli_from_midi_and_inpaint_from_midi(tmp_path):
     # (sigma of that re-noising: sqrt(1 - alpha_bar[1]) = 0.041)
     assert kept.max() < 0.25 and kept.sum() / mask.sum() < 0.05 and mask.mean() > 0.1
     assert (np.abs(b - p2c) * (1 - mask)).sum() / (1 - mask).sum() > 2 * kept.sum() / mask.sum()      # the generated part is free
+
+
+def test_cli_sdf_pnotree_variant(tmp_path):
+    """cond_type pnotree through the CLI (ref:inference_sdf.py:676-680, 756-760): the song's piano-tree grid conditions a small denoiser
+    through the full-size PianoTreeEncoder (d_cond 2048), autoregressively; synthetic weights travel as one more packed blob."""
+    params = dict(PARAMS, model_name="small_pnotree", d_cond=2048, cond_type="pnotree", use_enc=True)
+    (tmp_path / "params.yaml").write_text(yaml.safe_dump(params))
+    song = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chord_example.mid")
+    out = tmp_path / "out"
+    argv = ["--custom_params_path", str(tmp_path / "params.yaml"), "--synthetic_weights", "--from_midi", song, "--length", "2", "--autoreg",
+            "--ddim", "--ddim_steps", "4", "--uncond_scale", "2.0", "--seed", "9", "--output_dir", str(out)]
+    assert inference_sdf.main(argv) == 0
+    a = np.load(out / sorted(f for f in os.listdir(out) if f.endswith(".npy"))[0])
+    assert a.shape == (4, 2, 64, 128) and np.isfinite(a).all()
+    with pytest.raises(SystemExit, match="piano-tree grid"):
+        np.savez(tmp_path / "c.npz", chord=synth.chords(1, 1))
+        inference_sdf.main(argv[:3] + ["--cond_npz", str(tmp_path / "c.npz")] + argv[5:])

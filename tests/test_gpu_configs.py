@@ -254,3 +254,24 @@ def test_ddim_quad_and_eta_full_size(chd8bar, disc, eta):
     err = (got.cpu() - ref).abs().max().item()
     print(f"DDIM {disc} eta={eta} full size max-abs-diff vs oracle:", err)
     assert err < TOL_TRAJ
+
+
+def test_sdf_pnotree_full_size():
+    """params/sdf_pnotree.yaml: cond = PianoTreeEncoder means of the four 2-bar segments (d_cond 2048); full-size eps against the oracle,
+    then one sampler step and the CLI's condition plumbing (synthetic grids)."""
+    from polyffusion_amd.inference_sdf import encode_conditions
+    p = preset("sdf_pnotree")
+    assert p.d_cond == 2048 and p.cond_type == "pnotree"
+    m = synthetic_model(p)
+    m.ldm.eps_model.set_precision("bf16x3")
+    grid = torch.from_numpy(synth.pnotree(2, 77)).cuda()
+    cond, cond_mid = encode_conditions(m, p, None, None, True, pnotree=grid)
+    assert cond.shape == (2, 1, 2048) and cond_mid.shape == (2, 1, 2048)
+    x = torch.from_numpy(synth.gaussian((2, 2, 128, 128), 78)).cuda()
+    t = torch.tensor([5, 911]).cuda()
+    eps = m.ldm(x, t, cond)
+    with torch.no_grad():
+        ref = oracle_model(UNetConfig(d_cond=2048))(x.cpu(), t.cpu(), cond.cpu())
+    err = (eps.cpu() - ref).abs().max().item()
+    print("sdf_pnotree eps max-abs-diff vs oracle:", err)
+    assert err < TOL_EPS

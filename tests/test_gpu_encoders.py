@@ -68,3 +68,24 @@ def test_encoders_at_the_batch_sizes_of_the_configs(B):
     assert zt.shape == (B, 1, 1024)
     assert (zt.cpu() - encoders_ref.encode_txt(wt, pr)).abs().max() < 1e-4
     assert torch.equal(zt, m._encode_txt(pr.cuda()))          # bit-reproducible
+
+
+def test_pianotree_encoder_vs_reference_golden(golden):
+    """PianoTreeEncoder (dl_modules/pianotree_enc.py) through Polyffusion_SDF._encode_pnotree (models/model_sdf.py:138-151) on the HIP
+    kernels against the REAL reference's output (tests/golden/pnotree.npz): variable-length note GRU incl. a crowded and an empty song."""
+    from polyffusion_amd.model_sdf import PianoTreeEncoder
+    from polyffusion_amd.weights import synth_pianotree_encoder_state
+    g = golden("pnotree.npz")
+    pe = PianoTreeEncoder().load_state_dict(synth_pianotree_encoder_state(0))
+    m = Polyffusion_SDF(None, "pnotree", pnotree_enc=pe)
+    grid = torch.from_numpy(np.stack([g[f"grid{i}"] for i in range(4)])).cuda()
+    z = m._encode_pnotree(grid)
+    assert z.shape == (4, 1, 2048)
+    assert np.abs(z.cpu().numpy() - g["z"]).max() < 1e-4
+    dist, _, lengths = pe(grid[:, :32])
+    assert np.array_equal(lengths.numpy(), g["lengths_seg0"])
+    assert torch.equal(z, m._encode_pnotree(grid))
+    # config-size batch against the oracle
+    wp = unet_ref.to_torch(synth_pianotree_encoder_state(0))
+    big = torch.from_numpy(synth.pnotree(16, 900))
+    assert (m._encode_pnotree(big.cuda()).cpu() - encoders_ref.encode_pnotree(wp, big)).abs().max() < 1e-4

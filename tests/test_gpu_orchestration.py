@@ -80,11 +80,8 @@ def test_dummy_cond_input_and_masks_on_device(golden):
         p = Params(dict(img_h=128, img_w=128, cond_type=ct, chd_n_step=32, chd_input_dim=36))
         outs = dummy_cond_input(3, p)
         want = g[f"dummy_{ct}_shapes"]
-        # the pnotree slot (index 1) is outside the rebuilt path: None here, [3,128,20,6] zeros in the reference
         for i, o in enumerate(outs):
-            if i == 1:
-                assert o is None
-            elif want[i][0] < 0:
+            if want[i][0] < 0:
                 assert o is None
             else:
                 assert o.is_cuda and list(o.shape) == [int(v) for v in want[i][: o.dim()]] and float(o.abs().sum()) == 0.0

@@ -42,6 +42,7 @@ def main():
         p2, _pn, ch, pm = ds.get_whole_song_data()
         out[f"{name}_seed"], out[f"{name}_bars"] = seed, bars
         out[f"{name}_prmat2c"], out[f"{name}_chord"], out[f"{name}_prmat"] = p2.numpy(), ch.numpy(), pm.numpy()
+        out[f"{name}_pnotree"] = _pn.numpy().astype(np.int16)          # [S, 128, 20, 6] piano-tree grid (values < 131)
         s0 = ds[1]
         out[f"{name}_item1_prmat2c"], out[f"{name}_item1_chord"], out[f"{name}_item1_prmat"] = s0[0], s0[2], s0[3]
     path = os.path.join(REPO, "tests", "golden", "datasample.npz")
