@@ -200,6 +200,13 @@ int pf_ln_planes(const float* x, int rows, int c, float eps, const float* gamma,
 int pf_mlp_geglu_fused(const float* x, int batch, int l, const float* ln_gamma, const float* ln_beta, float ln_eps,
                        const void* w1_bf16x3, const float* b1, const void* w2_bf16x3, const float* b2,
                        float* out, void* out_planes, void* stream);
+/* The same launch with the SpatialTransformer's closing 1x1 convolution chained on (unet_attention.py:77-79 `proj_out(x) + x_in` after the
+ * last transformer layer): out = res3 + b3 + W3 . (x + ff(norm3(x))), the ff result never leaving the chip.  w3_bf16x3: bf16x3 packing
+ * of proj_out ([256][256]); res3: the block input [batch*l][256]; stats3 (optional): per-64-row-tile channel (sum, sumsq) of `out`,
+ * [batch][l/64][256][2], for the GroupNorm that consumes it.  Bit-identical to pf_mlp_geglu_fused(out_planes) + pf_conv2d(a_planes, res). */
+int pf_mlp_geglu_proj_fused(const float* x, int batch, int l, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                            const void* w1_bf16x3, const float* b1, const void* w2_bf16x3, const float* b2,
+                            const void* w3_bf16x3, const float* b3, const float* res3, float* out, float* stats3, void* stream);
 
 /* Implicit-GEMM convolution / linear on NHWC with fused prologue and epilogue (fp32 MFMA).
  *   ks 1|3, stride 1|2, ups 0|1 (nearest x2 folded into the input read, unet.py:236-238)

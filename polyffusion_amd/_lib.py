@@ -112,6 +112,7 @@ SIGNATURES = {
     "pf_ln_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_mlp_geglu_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_mlp_geglu_proj_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 10),
     "pf_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "pf_conv_stats_tiles": (C.c_int, [C.POINTER(ConvArgs)]),
     "pf_conv_splitk_ws_bytes": (C.c_size_t, [C.POINTER(ConvArgs)]),

@@ -20,11 +20,15 @@ namespace pf {
 struct MlpX {
   const float* gamma; const float* beta; float eps;
   const __bf16* w1; const float* b1;    // GeGLU projection: bf16x3 packing [K/8][plane][2048][8], columns value|gate interleaved by 32
+  // TAIL (the SpatialTransformer's proj_out chained on, unet_attention.py:77-79): ff output + residual stay on chip as the A operand of
+  // one more 256 x 256 projection; ConvP then describes THAT projection's epilogue (bias, block input as residual, statistics)
+  const float* b2;                      // ff.net.2 bias (the ff residual is p.x0, the LayerNorm input)
+  const __bf16* w3;                     // proj_out: bf16x3 packing [32][plane][256][8]
 };
 
 typedef __bf16 bf16x4_m __attribute__((ext_vector_type(4)));
 
-template <int RING>
+template <int RING, bool TAIL>
 __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
   constexpr int BM = 64, C = 256, HID = 1024, HS = 64, NSL = HID / HS;
   constexpr int A_B = BM * C * 4;           // 64 KB: LayerNorm planes, [chunk 8][plane 2][row 64][64 B]
@@ -63,10 +67,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g1 + ((size_t)((c * 4 + q) * 2) * 2048 + js * 128) * 8),
                                      (__attribute__((address_space(3))) void*)(sR + pos * SLOT_B + wave * 1024 + q * 4096), 16, 0, 0);
   };
-  auto issue_w2 = [&](int js, int c, int pos, int q) {   // 16-deep step c of ff2 slice js
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g2 + (size_t)(((js * 8 + c * 2 + (q >> 1)) * 2 + (q & 1)) * 256) * 8),
+  auto issue_wn = [&](const __bf16* gbase, int kstep, int pos, int q) {   // 16-deep step `kstep` of a [K][256] matrix
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + (size_t)(((kstep * 2 + (q >> 1)) * 2 + (q & 1)) * 256) * 8),
                                      (__attribute__((address_space(3))) void*)(sR + pos * SLOT_B + wave * 1024 + q * 4096), 16, 0, 0);
   };
+  auto issue_w2 = [&](int js, int c, int pos, int q) { issue_wn(g2, js * 4 + c, pos, q); };   // 16-deep step c of ff2 slice js
+  const __bf16* g3 = TAIL ? e.w3 + (size_t)tid * 8 : g2;
   // Slot order of the whole kernel (the GeGLU of slice j runs inside the MFMA gaps of ff1 slice j+1, so ff2 lags one slice):
   //   P0..P7 = ff1 slice 0 | for j = 0..14: M(j,0..7) = ff1 slice j+1, M(j,8..11) = ff2 slice j | F0..F3 = ff2 slice 15
   // every group is a multiple of RING slots, so a slot's ring position is its index within the group mod RING.
@@ -142,6 +148,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
   bf16x8 gal[2], gah[2], gbh[2][4], gbl[2][4];                // ff2 slot: [set]([fn])
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define IC(N) std::integral_constant<int, (N)>{}
+#define FROM_H std::false_type{}
+#define FROM_A std::true_type{}
+#define OPEN_B std::true_type{}
+#define OPEN_A std::false_type{}
   // n-th fragment read (in consumption order: al, bh0, bh1, ah, bl0, bl1 per K step) of ff1 slot (chunk CC, ring position RP) into set S
   auto ld1 = [&](auto S_, auto CC_, auto RP_, auto N_) {
     constexpr int S = S_.value, CC = CC_.value, RP = RP_.value, ks = N_.value / 6, m = N_.value % 6;
@@ -151,12 +161,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
     else fbl[S][ks][m - 4] = lds_read128<RP * SLOT_B + ((4 * ks + 1) * 128 + (m - 4) * 32) * 16>(wb1);
   };
   // ff2 slot (16-deep step CC of the slice, ring position RP): n = 0..3 bh, 4..7 bl (weights), 8 al, 9 ah (the GeGLU product in sH)
-  auto ld2 = [&](auto S_, auto CC_, auto RP_, auto N_) {
+  auto ld2 = [&](auto S_, auto CC_, auto RP_, auto N_, auto FROMA_) {
     constexpr int S = S_.value, CC = CC_.value, RP = RP_.value, n = N_.value;
+    constexpr bool fa = decltype(FROMA_)::value;    // A operand from the resident 64 x 256 planes (sA) instead of the slice product (sH)
     if constexpr (n < 4) gbh[S][n] = lds_read128<RP * SLOT_B + (n * 32) * 16>(wb2);
     else if constexpr (n < 8) gbl[S][n - 4] = lds_read128<RP * SLOT_B + (256 + (n - 4) * 32) * 16>(wb2);
-    else if constexpr (n == 8) gal[S] = lds_read128<(CC >> 1) * CH_B + LO_B>((CC & 1) ? hb1 : hb0);
-    else gah[S] = lds_read128<(CC >> 1) * CH_B>((CC & 1) ? hb1 : hb0);
+    else if constexpr (n == 8) gal[S] = lds_read128<(CC >> 1) * CH_B + LO_B>(fa ? ((CC & 1) ? ab1 : ab0) : ((CC & 1) ? hb1 : hb0));
+    else gah[S] = lds_read128<(CC >> 1) * CH_B>(fa ? ((CC & 1) ? ab1 : ab0) : ((CC & 1) ? hb1 : hb0));
   };
   // n-th MFMA of a slot: per K step X X Z Z Y Y (ff1, two column fragments) / X X X X Z Z Z Z Y Y Y Y (ff2, four)
   auto mf1 = [&](auto S_, auto N_) {
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
       if constexpr (n == 1) SLOT_SYNC();
       if constexpr (m >= 0 && m < 4) {
         if constexpr (next.value == 0) { ld1(IC(NS), IC(c + 1), IC(rpn), IC(3 * m)); ld1(IC(NS), IC(c + 1), IC(rpn), IC(3 * m + 1)); ld1(IC(NS), IC(c + 1), IC(rpn), IC(3 * m + 2)); }
-        else if constexpr (next.value == 1) { ld2(IC(0), IC(0), IC(rpn), IC(2 * m)); ld2(IC(0), IC(0), IC(rpn), IC(2 * m + 1)); }
+        else if constexpr (next.value == 1) { ld2(IC(0), IC(0), IC(rpn), IC(2 * m), FROM_H); ld2(IC(0), IC(0), IC(rpn), IC(2 * m + 1), FROM_H); }
         else { ld1(IC(NS), IC(0), IC(rpn), IC(3 * m)); ld1(IC(NS), IC(0), IC(rpn), IC(3 * m + 1)); ld1(IC(NS), IC(0), IC(rpn), IC(3 * m + 2)); }
       }
       if constexpr (n >= 6 && n < 10) dma(cc, IC(n - 6));
@@ -271,12 +282,15 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
     });
   };
   // one ff2 slot (16-deep step c).  NEXT: 0 = step c+1, 1 = chunk 0 of an ff1 slice, 2 = step 0 of the next ff2 slice (weights only), 3 = nothing
-  auto ff2_slot = [&](auto cc, auto next, auto&& dma, auto&& extra) {
+  auto ff2_slot = [&](auto cc, auto next, auto&& dma, auto&& extra, auto froma, auto openb) {
     constexpr int c = cc.value, S = c & 1, NS = S ^ 1, rpn = (c + 1) % RING;
     FRAGS_READY();
-    if constexpr (c == 0) {   // the barrier also publishes the GeGLU product, whose fragments can only be read now (exposed once per slice)
+    if constexpr (c == 0) {   // the barrier also publishes the A operand just written (GeGLU product / chained input), readable only now
       SLOT_SYNC();
-      ld2(IC(0), IC(0), IC(0), IC(8)); ld2(IC(0), IC(0), IC(0), IC(9));
+      // OPEN_B: the pass starts behind compiler-scheduled code (or a loop exit): nothing may be in flight across that, so the weight
+      // fragments of its first step are read here too instead of during the previous slot
+      if constexpr (decltype(openb)::value) static_for<0, 8>([&](auto n) { ld2(IC(0), IC(0), IC(0), n, froma); });
+      ld2(IC(0), IC(0), IC(0), IC(8), froma); ld2(IC(0), IC(0), IC(0), IC(9), froma);
       FRAGS_READY();
     }
     static_for<0, 12>([&](auto nn) {
@@ -284,9 +298,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
       mf2(IC(S), nn); SB();
       if constexpr (n == 1 && c != 0) SLOT_SYNC();
       if constexpr (m >= 0) {
-        if constexpr (next.value == 0) { if constexpr (m < 5) { ld2(IC(NS), IC(c + 1), IC(rpn), IC(2 * m)); ld2(IC(NS), IC(c + 1), IC(rpn), IC(2 * m + 1)); } }
+        if constexpr (next.value == 0) { if constexpr (m < 5) { ld2(IC(NS), IC(c + 1), IC(rpn), IC(2 * m), froma); ld2(IC(NS), IC(c + 1), IC(rpn), IC(2 * m + 1), froma); } }
         else if constexpr (next.value == 1) { if constexpr (m < 4) { ld1(IC(NS), IC(0), IC(rpn), IC(3 * m)); ld1(IC(NS), IC(0), IC(rpn), IC(3 * m + 1)); ld1(IC(NS), IC(0), IC(rpn), IC(3 * m + 2)); } }
-        else if constexpr (next.value == 2) { if constexpr (m < 4) { ld2(IC(NS), IC(0), IC(rpn), IC(2 * m)); ld2(IC(NS), IC(0), IC(rpn), IC(2 * m + 1)); } }
+        else if constexpr (next.value == 2) { if constexpr (m < 4) { ld2(IC(NS), IC(0), IC(rpn), IC(2 * m), FROM_H); ld2(IC(NS), IC(0), IC(rpn), IC(2 * m + 1), FROM_H); } }
       }
       if constexpr (n >= 6 && n < 10) dma(cc, IC(n - 6));
       extra(nn);
@@ -352,28 +366,83 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
         else if (j < NSL - 2) issue_w1(j + 2, t - 12, t % RING, q);
         else issue_w2(NSL - 1, t - 12, t % RING, q);
       };
-      ff2_slot(cc, IC(0), dma, no_extra);
+      ff2_slot(cc, IC(0), dma, no_extra, FROM_H, OPEN_A);
     });
     {
       auto dma = [&](auto, auto q_) {
         constexpr int q = q_.value;   // slot 14 of the iteration = slot 2 of the next group
         if (j < NSL - 2) issue_w1(j + 2, 2, 2, q); else issue_w2(NSL - 1, 2, 2, q);
       };
-      if (j < NSL - 2) ff2_slot(IC(3), IC(1), dma, take_acc); else ff2_slot(IC(3), IC(2), dma, take_acc);
+      // always "next = chunk 0 of an ff1 slice": after the last iteration those fragments are never used (ring position 0 then holds an
+      // ff2 step) - one instruction stream for every j keeps hidden loads out of data-dependent control flow; F0 reads its own weights
+      ff2_slot(IC(3), IC(1), dma, take_acc, FROM_H, OPEN_A);
     }
   }
   // ---- F: GeGLU of the last slice (nothing left to hide it behind), then ff2 slice 15 ----
   FRAGS_READY();
+  // the fragment reads of an ff1 slice that never runs are dead values to the compiler: keep their registers until the wait above
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    asm volatile("" ::"v"(fal[0][k]), "v"(fah[0][k]));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(fbh[0][k][i]), "v"(fbl[0][k][i]));
+  }
   bv = bvn; bg = bgn;
   static_for<0, NPIECE>([&](auto k) { geglu_piece(k); });
   SB();
   static_for<0, 4>([&](auto cc) {
-    auto dma = [&](auto, auto q_) { issue_w2(NSL - 1, 3, (cc.value + 3) % RING, q_.value); };   // F3 once, then re-fetches nobody reads (keeps vmcnt(4) meaningful)
-    if constexpr (cc.value < 3) ff2_slot(cc, IC(0), dma, no_extra); else ff2_slot(cc, IC(3), dma, no_extra);
+    auto dma = [&](auto, auto q_) {   // F3, then (TAIL) the first proj_out steps - otherwise re-fetches nobody reads (keeps vmcnt(4) meaningful)
+      constexpr int c = decltype(cc)::value, q = decltype(q_)::value;
+      if constexpr (c == 0 || !TAIL) issue_w2(NSL - 1, 3, (c + 3) % RING, q); else issue_wn(g3, c - 1, (c + 3) % RING, q);
+    };
+    if constexpr (cc.value < 3) ff2_slot(cc, IC(0), dma, no_extra, FROM_H, OPEN_B);
+    else ff2_slot(cc, IC(3), dma, no_extra, FROM_H, OPEN_B);
   });
+  if constexpr (TAIL) {
+    // ---- x2 = ff output + bias + x, straight from the accumulators into the resident A planes (same lane-quad transpose / split / 8-byte
+    // stores as the GeGLU product); the ff1 slices are done with sA, and x2 itself is needed nowhere else (the layer's only consumer is
+    // proj_out).  Then 16 more 16-deep steps against proj_out's weights.
+    {
+      const int cq = (lane & 31) & ~3;
+      f32x4 b4[4];
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) b4[fn] = *reinterpret_cast<const f32x4*>(e.b2 + wn * 128 + fn * 32 + cq);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = wm * 32 + 8 * q + 4 * (lane >> 5) + (lane & 3);
+        f32x4 r4[4];
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) r4[fn] = *reinterpret_cast<const f32x4*>(p.x0 + (row0 + row) * C + wn * 128 + fn * 32 + cq);
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+          f32x4 v = {acc2[0][fn][4 * q], acc2[0][fn][4 * q + 1], acc2[0][fn][4 * q + 2], acc2[0][fn][4 * q + 3]};
+          quad_transpose(v, lane);
+          v = v + (b4[fn] + r4[fn]);        // acc + (bias + residual): the order of conv_epilogue's plane-pair path, which this replaces
+          const bf16x4_m hi = __builtin_convertvector(v, bf16x4_m);
+          const bf16x4_m lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4_m);
+          unsigned char* d = sA + (wn * 4 + fn) * CH_B + row * 64 + (((cq >> 3) ^ ((row >> 2) & 3)) * 16) + ((cq >> 2) & 1) * 8;
+          *reinterpret_cast<bf16x4_m*>(d) = hi;
+          *reinterpret_cast<bf16x4_m*>(d + LO_B) = lo;
+        }
+      }
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[0][fn][r] = 0.f;
+    }
+    SB();
+    static_for<0, 16>([&](auto cc) {
+      auto dma = [&](auto, auto q_) { issue_wn(g3, cc.value + 3 < 16 ? cc.value + 3 : 15, (cc.value + 3) % RING, q_.value); };
+      if constexpr (cc.value < 15) ff2_slot(cc, IC(0), dma, no_extra, FROM_A, OPEN_B); else ff2_slot(cc, IC(3), dma, no_extra, FROM_A, OPEN_B);
+    });
+  }
 #undef FRAGS_READY
 #undef SLOT_SYNC
 #undef IC
+#undef FROM_H
+#undef FROM_A
+#undef OPEN_B
+#undef OPEN_A
 #undef SB
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
@@ -381,29 +450,39 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
 }
 
 // x: fp32 [B*L][256] (LayerNorm input AND residual); w1 / w2: bf16x3 packings of ff.net.0.proj (GeGLU-interleaved) and ff.net.2
+// x: fp32 [B*L][256] (LayerNorm input AND residual); w1 / w2: bf16x3 packings of ff.net.0.proj (GeGLU-interleaved) and ff.net.2.
+// w3 != nullptr chains the SpatialTransformer's proj_out (bf16x3 packing of the [256][256] 1x1 conv, bias b3) and its residual `res3`
+// (the block input) onto the tile: out = res3 + b3 + W3 . (x + ff(LN(x))), with the per-64-row-tile channel statistics in `stats3`.
 int launch_mlp_fused(const float* x, int batch, int l, const float* gamma, const float* beta, float eps, const void* w1, const float* b1,
-                     const void* w2, const float* b2, float* out, void* out_planes, hipStream_t stream) {
+                     const void* w2, const float* b2, float* out, void* out_planes, hipStream_t stream, const void* w3, const float* b3,
+                     const float* res3, float* stats3) {
   PF_REQUIRE(x && gamma && beta && w1 && b1 && w2 && b2 && (out || out_planes), "mlp_fused: null argument");
   PF_REQUIRE(batch > 0 && l > 0 && l % 64 == 0, "mlp_fused: rows per sample must be a multiple of 64 (got %d)", l);
+  PF_REQUIRE(!w3 || (b3 && res3 && out && !out_planes), "mlp_fused: the chained projection needs its bias, its residual and an fp32 output");
   constexpr int RING = 4;
   ConvP p;
   memset(&p, 0, sizeof p);
   p.x0 = x; p.c0 = 256; p.B = batch; p.Hin = 1; p.Win = l; p.Hout = 1; p.Wout = l;
   p.w = w2; p.N = 256; p.Npad = 256;
-  p.bias = b2; p.res = x; p.ld_res = 256;
-  p.out = out; p.ld_out = 256; p.out_planes = out_planes;
+  p.bias = w3 ? b3 : b2; p.res = w3 ? res3 : x; p.ld_res = 256;
+  p.out = out; p.ld_out = 256; p.out_planes = out_planes; p.stats = w3 ? stats3 : nullptr;
   p.ksplit = 1;
   p.tiles_x = l / 64; p.tiles_y = 1; p.nt = 1;
   conv_fill_divs(p);
-  MlpX e{gamma, beta, eps, static_cast<const __bf16*>(w1), b1};
+  MlpX e{gamma, beta, eps, static_cast<const __bf16*>(w1), b1, b2, static_cast<const __bf16*>(w3)};
   constexpr size_t main_b = 65536 + RING * 16384 + 16384 + 8192;
   constexpr size_t epi_b = 65536 + (size_t)64 * (256 + 8) * 4;   // planes output: the fp32 tile is transposed through the ring region
   constexpr size_t lds = main_b > epi_b ? main_b : epi_b;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = mlp_bf3_kernel<RING>;
+  auto set_lds = [&](const void* k) { return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); };
   static bool done = false;
-  if (!done) { PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
-  hipLaunchKernelGGL(kern, dim3(batch * (l / 64)), dim3(256), lds, stream, p, e);
+  if (!done) {
+    PF_CHECK_HIP(set_lds(reinterpret_cast<const void*>(mlp_bf3_kernel<RING, false>)));
+    PF_CHECK_HIP(set_lds(reinterpret_cast<const void*>(mlp_bf3_kernel<RING, true>)));
+    done = true;
+  }
+  if (w3) hipLaunchKernelGGL((mlp_bf3_kernel<RING, true>), dim3(batch * (l / 64)), dim3(256), lds, stream, p, e);
+  else hipLaunchKernelGGL((mlp_bf3_kernel<RING, false>), dim3(batch * (l / 64)), dim3(256), lds, stream, p, e);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }

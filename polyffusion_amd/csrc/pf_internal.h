@@ -47,7 +47,8 @@ int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, 
 int launch_gemm_planes(const pf_conv_args& a, hipStream_t stream);   // called by launch_conv when a.a_planes
 // out = x + ff2(GeGLU(ff1(LayerNorm(x)))) for C = 256, hidden 1024, as one launch (mlp_fused_bf3.hip); w1 / w2 = bf16x3 packings
 int launch_mlp_fused(const float* x, int batch, int l, const float* gamma, const float* beta, float eps, const void* w1, const float* b1,
-                     const void* w2, const float* b2, float* out, void* out_planes, hipStream_t stream);
+                     const void* w2, const float* b2, float* out, void* out_planes, hipStream_t stream, const void* w3 = nullptr,
+                     const float* b3 = nullptr, const float* res3 = nullptr, float* stats3 = nullptr);
 
 size_t gn_scratch_bytes(int batch, int c, int hw);
 int launch_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batch, int hw, int groups, float eps,

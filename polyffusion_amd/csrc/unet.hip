@@ -619,10 +619,24 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
     last_planes = planes && (i + 1 == L.tbs.size());
     if (planes && mlp_fused_wanted(C, hw, M)) {
       // one launch: LayerNorm, GeGLU projection, output projection and residual per 64-row tile, hidden tensor kept on chip
+      if (last_planes) {
+        // the block's proj_out rides on the same launch: ff output + residual stay in LDS as its A operand, the result lands in `out`
+        // together with the 64-row-tile statistics the next GroupNorm reads
+        const int nt = hw / 64;
+        float* sb = c.palloc((size_t)B * nt * C * 2);
+        c.prof_begin(PF_K_GEMM, 2.0 * M * ((double)C * 8 * C + 4.0 * C * C + (double)C * C));
+        if (!c.dry && c.rc == PF_OK)
+          c.rc = launch_mlp_fused(t1, B, hw, c.w(t.n3g), c.w(t.n3b), 1e-5f, c.w(t.ff1w) + (size_t)C * 8 * C, c.w(t.ff1b),
+                                  c.w(t.ff2w) + (size_t)4 * C * C, c.w(t.ff2b), out, nullptr, c.s, c.w(L.pout_w) + (size_t)C * C, c.w(L.pout_b), x, sb);
+        c.prof_end();
+        Tn ot;
+        ot.d = out; ot.c = C; ot.st = sb; ot.nt = nt;
+        return ot;
+      }
       c.prof_begin(PF_K_GEMM, 2.0 * M * ((double)C * 8 * C + 4.0 * C * C));
       if (!c.dry && c.rc == PF_OK)
         c.rc = launch_mlp_fused(t1, B, hw, c.w(t.n3g), c.w(t.n3b), 1e-5f, c.w(t.ff1w) + (size_t)C * 8 * C, c.w(t.ff1b),
-                                c.w(t.ff2w) + (size_t)4 * C * C, c.w(t.ff2b), t2, last_planes ? (void*)t2 : nullptr, c.s);
+                                c.w(t.ff2w) + (size_t)4 * C * C, c.w(t.ff2b), t2, nullptr, c.s);
       c.prof_end();
       std::swap(t0, t2);
       continue;
@@ -934,6 +948,13 @@ int pf_mlp_geglu_fused(const float* x, int batch, int l, const float* ln_gamma, 
                        const void* w1_bf16x3, const float* b1, const void* w2_bf16x3, const float* b2,
                        float* out, void* out_planes, void* stream) {
   return launch_mlp_fused(x, batch, l, ln_gamma, ln_beta, ln_eps, w1_bf16x3, b1, w2_bf16x3, b2, out, out_planes, (hipStream_t)stream);
+}
+int pf_mlp_geglu_proj_fused(const float* x, int batch, int l, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                            const void* w1_bf16x3, const float* b1, const void* w2_bf16x3, const float* b2,
+                            const void* w3_bf16x3, const float* b3, const float* res3, float* out, float* stats3, void* stream) {
+  if (!w3_bf16x3) return set_error(PF_EINVAL, "pf_mlp_geglu_proj_fused: null projection weight");
+  return launch_mlp_fused(x, batch, l, ln_gamma, ln_beta, ln_eps, w1_bf16x3, b1, w2_bf16x3, b2, out, nullptr, (hipStream_t)stream, w3_bf16x3, b3,
+                          res3, stats3);
 }
 int pf_ln_planes(const float* x, int rows, int c, float eps, const float* gamma, const float* beta, void* planes, void* stream) {
   return launch_ln_planes(x, rows, c, eps, gamma, beta, planes, (hipStream_t)stream);
