@@ -207,6 +207,24 @@ int pf_mlp_geglu_fused(const float* x, int batch, int l, const float* ln_gamma, 
 int pf_mlp_geglu_proj_fused(const float* x, int batch, int l, const float* ln_gamma, const float* ln_beta, float ln_eps,
                             const void* w1_bf16x3, const float* b1, const void* w2_bf16x3, const float* b2,
                             const void* w3_bf16x3, const float* b3, const float* res3, float* out, float* stats3, void* stream);
+/* Everything of a BasicTransformerBlock that follows self-attention, per 64-token tile in ONE launch (unet_attention.py:115-124 with the
+ * n_cond == 1 cross-attention collapsed to a per-sample bias, optionally + SpatialTransformer.proj_out :77-79):
+ *     x1  = attn_planes . Wo + bo + cross_bias[sample] + x0          (attn1.to_out + residual; x1 is also written to `x1`)
+ *     x2  = x1 + ff(norm3(x1))
+ *     out = x2                          (w3 == NULL; fp32 `out` or plane pair `out_planes`)
+ *         = res3 + b3 + W3 . x2         (proj_out chained; `stats3` as in pf_mlp_geglu_proj_fused)
+ * attn_planes: pf_attention_bf16x3's o_planes; every weight is the bf16x3 packing of its [256][K] matrix (w1 GeGLU-interleaved).
+ * Bit-identical to pf_conv2d(a_planes, res) + pf_mlp_geglu(_proj)_fused. */
+typedef struct pf_tblock_tail_args {
+  const void* attn_planes; const void* wo; const float* bo; const float* cross_bias; int32_t ld_cross_bias; const float* x0;
+  float* x1;
+  int32_t batch, l;
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  const void* w1; const float* b1; const void* w2; const float* b2;
+  const void* w3; const float* b3; const float* res3; float* stats3;
+  float* out; void* out_planes;
+} pf_tblock_tail_args;
+int pf_transformer_tail_fused(const pf_tblock_tail_args* a, void* stream);
 
 /* Implicit-GEMM convolution / linear on NHWC with fused prologue and epilogue (fp32 MFMA).
  *   ks 1|3, stride 1|2, ups 0|1 (nearest x2 folded into the input read, unet.py:236-238)

@@ -35,6 +35,14 @@ class DdimCoef(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("s1m", "sqrt_a", "sqrt_aprev", "dir_coef", "sigma", "q_sqrt_a", "q_s1m")]
 
 
+class TBlockTailArgs(C.Structure):
+    """pf_tblock_tail_args (include/pfhip.h)."""
+    _fields_ = [("attn_planes", C.c_void_p), ("wo", C.c_void_p), ("bo", C.c_void_p), ("cross_bias", C.c_void_p), ("ld_cross_bias", C.c_int32),
+                ("x0", C.c_void_p), ("x1", C.c_void_p), ("batch", C.c_int32), ("l", C.c_int32), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
+                ("ln_eps", C.c_float), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p),
+                ("b3", C.c_void_p), ("res3", C.c_void_p), ("stats3", C.c_void_p), ("out", C.c_void_p), ("out_planes", C.c_void_p)]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [
         ("x0", C.c_void_p), ("c0", C.c_int32), ("x1", C.c_void_p), ("c1", C.c_int32),
@@ -113,6 +121,7 @@ SIGNATURES = {
     "pf_mlp_geglu_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_mlp_geglu_proj_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 10),
+    "pf_transformer_tail_fused": (C.c_int, [C.POINTER(TBlockTailArgs), C.c_void_p]),
     "pf_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "pf_conv_stats_tiles": (C.c_int, [C.POINTER(ConvArgs)]),
     "pf_conv_splitk_ws_bytes": (C.c_size_t, [C.POINTER(ConvArgs)]),

@@ -45,10 +45,12 @@ int launch_attention(const float* q, int ldq, const float* k, int ldk, const flo
 
 int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, hipStream_t stream);
 int launch_gemm_planes(const pf_conv_args& a, hipStream_t stream);   // called by launch_conv when a.a_planes
+// attn1's to_out chained in front of the fused feed-forward launch: x1 = a_planes . w + bias + sbias[sample] + res (unet_attention.py:115, 210-212)
+struct MlpHead { const void* a_planes; const void* w; const float* bias; const float* sbias; int ld_sbias; const float* res; };
 // out = x + ff2(GeGLU(ff1(LayerNorm(x)))) for C = 256, hidden 1024, as one launch (mlp_fused_bf3.hip); w1 / w2 = bf16x3 packings
 int launch_mlp_fused(const float* x, int batch, int l, const float* gamma, const float* beta, float eps, const void* w1, const float* b1,
                      const void* w2, const float* b2, float* out, void* out_planes, hipStream_t stream, const void* w3 = nullptr,
-                     const float* b3 = nullptr, const float* res3 = nullptr, float* stats3 = nullptr);
+                     const float* b3 = nullptr, const float* res3 = nullptr, float* stats3 = nullptr, const MlpHead* head = nullptr);
 
 size_t gn_scratch_bytes(int batch, int c, int hw);
 int launch_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batch, int hw, int groups, float eps,

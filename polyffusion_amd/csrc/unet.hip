@@ -584,7 +584,16 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
       c.rc = planes ? launch_attention_bf3(qkv, nullptr, C, att, B, nh, hw, c.s)   // att as hi/lo planes for the to_out GEMM
                     : launch_attention(qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, att, C, B, nh, dh, hw, hw, c.s);
     c.prof_end();
-    {
+    last_planes = planes && (i + 1 == L.tbs.size());
+    const bool fuse_mlp = planes && mlp_fused_wanted(C, hw, M);
+    // to_out can ride in front of the feed-forward launch (pf_transformer_tail_fused; its LayerNorm input is then made on chip).  Measured
+    // at B = 16: neutral end to end (189.0 vs 189.0 steps/s, same box) - the 256 workgroups fetch their attention planes and residual rows (192 KB each) in one un-overlapped
+    // burst and run the 16 extra steps at one wave per SIMD, which costs what the separate two-workgroups-per-CU launch cost.  Off unless
+    // PF_MLP_HEAD=1.
+    static const bool head_on = [] { const char* e = getenv("PF_MLP_HEAD"); return e && atoi(e) != 0; }();
+    const bool fuse_head = head_on && fuse_mlp && c.n_cond == 1;
+    MlpHead head{att, c.w(t.o1w) + (size_t)C * C, c.w(t.o1b), c.dry ? nullptr : cross_all + t.cross_off, c.u->cross_total, t0};
+    if (!fuse_head) {
       pf_conv_args a = conv_base(att, C, nullptr, 0, B, 1, hw, 1, c.w(t.o1w), C, t1);
       a.bias = c.w(t.o1b); a.res = t0; a.ld_res = C; a.a_planes = planes ? 1 : 0;
       if (c.n_cond == 1) {  // x = attn2(LN2(x), c) + x collapses to a per-sample bias (softmax over one key == 1)
@@ -616,27 +625,28 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
       std::swap(t1, t2);
     }
     // x = ff(LN3(x)) + x
-    last_planes = planes && (i + 1 == L.tbs.size());
-    if (planes && mlp_fused_wanted(C, hw, M)) {
+    if (fuse_mlp) {
       // one launch: LayerNorm, GeGLU projection, output projection and residual per 64-row tile, hidden tensor kept on chip
       if (last_planes) {
         // the block's proj_out rides on the same launch: ff output + residual stay in LDS as its A operand, the result lands in `out`
         // together with the 64-row-tile statistics the next GroupNorm reads
         const int nt = hw / 64;
         float* sb = c.palloc((size_t)B * nt * C * 2);
-        c.prof_begin(PF_K_GEMM, 2.0 * M * ((double)C * 8 * C + 4.0 * C * C + (double)C * C));
+        c.prof_begin(PF_K_GEMM, 2.0 * M * ((double)C * 8 * C + 4.0 * C * C + (double)C * C + (fuse_head ? (double)C * C : 0.0)));
         if (!c.dry && c.rc == PF_OK)
           c.rc = launch_mlp_fused(t1, B, hw, c.w(t.n3g), c.w(t.n3b), 1e-5f, c.w(t.ff1w) + (size_t)C * 8 * C, c.w(t.ff1b),
-                                  c.w(t.ff2w) + (size_t)4 * C * C, c.w(t.ff2b), out, nullptr, c.s, c.w(L.pout_w) + (size_t)C * C, c.w(L.pout_b), x, sb);
+                                  c.w(t.ff2w) + (size_t)4 * C * C, c.w(t.ff2b), out, nullptr, c.s, c.w(L.pout_w) + (size_t)C * C, c.w(L.pout_b), x, sb,
+                                  fuse_head ? &head : nullptr);
         c.prof_end();
         Tn ot;
         ot.d = out; ot.c = C; ot.st = sb; ot.nt = nt;
         return ot;
       }
-      c.prof_begin(PF_K_GEMM, 2.0 * M * ((double)C * 8 * C + 4.0 * C * C));
+      c.prof_begin(PF_K_GEMM, 2.0 * M * ((double)C * 8 * C + 4.0 * C * C + (fuse_head ? (double)C * C : 0.0)));
       if (!c.dry && c.rc == PF_OK)
         c.rc = launch_mlp_fused(t1, B, hw, c.w(t.n3g), c.w(t.n3b), 1e-5f, c.w(t.ff1w) + (size_t)C * 8 * C, c.w(t.ff1b),
-                                c.w(t.ff2w) + (size_t)4 * C * C, c.w(t.ff2b), t2, nullptr, c.s);
+                                c.w(t.ff2w) + (size_t)4 * C * C, c.w(t.ff2b), t2, nullptr, c.s, nullptr, nullptr, nullptr, nullptr,
+                                fuse_head ? &head : nullptr);
       c.prof_end();
       std::swap(t0, t2);
       continue;
@@ -955,6 +965,12 @@ int pf_mlp_geglu_proj_fused(const float* x, int batch, int l, const float* ln_ga
   if (!w3_bf16x3) return set_error(PF_EINVAL, "pf_mlp_geglu_proj_fused: null projection weight");
   return launch_mlp_fused(x, batch, l, ln_gamma, ln_beta, ln_eps, w1_bf16x3, b1, w2_bf16x3, b2, out, nullptr, (hipStream_t)stream, w3_bf16x3, b3,
                           res3, stats3);
+}
+int pf_transformer_tail_fused(const pf_tblock_tail_args* a, void* stream) {
+  if (!a || !a->attn_planes || !a->wo || !a->bo || !a->x0 || !a->x1) return set_error(PF_EINVAL, "pf_transformer_tail_fused: null argument");
+  MlpHead h{a->attn_planes, a->wo, a->bo, a->cross_bias, a->ld_cross_bias, a->x0};
+  return launch_mlp_fused(a->x1, a->batch, a->l, a->ln_gamma, a->ln_beta, a->ln_eps, a->w1, a->b1, a->w2, a->b2, a->out, a->out_planes,
+                          (hipStream_t)stream, a->w3, a->b3, a->res3, a->stats3, &h);
 }
 int pf_ln_planes(const float* x, int rows, int c, float eps, const float* gamma, const float* beta, void* planes, void* stream) {
   return launch_ln_planes(x, rows, c, eps, gamma, beta, planes, (hipStream_t)stream);
