@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
   // Slot hand-over of slot i, in two halves.  FRAGS_READY (before MFMA 0): every fragment of slot i has arrived in its registers.
   // SLOT_SYNC (after MFMA 1, so that the matrix pipe has work while the barrier resolves): this thread's pieces of slot i+1 have
   // landed (slot i+2 stays in flight); after the barrier slot i+1 is readable by everybody - its fragments are read behind MFMAs
-  // 2..5 - and the ring position of slot i-1 is free: it is refilled with slot i+3, one piece after each of MFMAs 6..9.
+  // 2..5 - and the ring position of slot i-1 is free: it is refilled with slot i+3, one piece after each of MFMAs 2..5
+  // (as early as the barrier allows: under the contention of 256 workgroups streaming the same weights the two-slot lead is not generous).
   // (sched_barriers on both sides: an MFMA is a pure register operation to the compiler and would otherwise move across the waits)
 #define FRAGS_READY() do { SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SB(); } while (0)
 #define SLOT_SYNC() do { SB(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); SB(); } while (0)
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
         else if constexpr (next.value == 1) { ld2(IC(0), IC(0), IC(rpn), IC(2 * m), FROM_H); ld2(IC(0), IC(0), IC(rpn), IC(2 * m + 1), FROM_H); }
         else { ld1(IC(NS), IC(0), IC(rpn), IC(3 * m)); ld1(IC(NS), IC(0), IC(rpn), IC(3 * m + 1)); ld1(IC(NS), IC(0), IC(rpn), IC(3 * m + 2)); }
       }
-      if constexpr (n >= 6 && n < 10) dma(cc, IC(n - 6));
+      if constexpr (n >= 2 && n < 6) dma(cc, IC(n - 2));
       if constexpr (fill.value && c * 12 + n < NPIECE) geglu_piece(IC(c * 12 + n));
       SB();
     });
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
         else if constexpr (next.value == 1) { if constexpr (m < 4) { ld1(IC(NS), IC(0), IC(rpn), IC(3 * m)); ld1(IC(NS), IC(0), IC(rpn), IC(3 * m + 1)); ld1(IC(NS), IC(0), IC(rpn), IC(3 * m + 2)); } }
         else if constexpr (next.value == 2) { if constexpr (m < 4) { ld2(IC(NS), IC(0), IC(rpn), IC(2 * m), FROM_H); ld2(IC(NS), IC(0), IC(rpn), IC(2 * m + 1), FROM_H); } }
       }
-      if constexpr (n >= 6 && n < 10) dma(cc, IC(n - 6));
+      if constexpr (n >= 2 && n < 6) dma(cc, IC(n - 2));
       extra(nn);
       SB();
     });
