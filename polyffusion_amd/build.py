@@ -12,6 +12,9 @@ SOURCES = ["conv_mfma.hip", "conv_bf16x3.hip", "gemm_planes_bf3.hip", "mlp_fused
 LIB = os.path.join(HERE, "libpfhip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + (["-DPF_TRACE"] if os.environ.get("PF_TRACE") else [])
+# per-file additions.  attention_bf3: the softmax of the 256-query kernel is dealt out between MFMAs one single-issue instruction at a
+# time; SLP vectorisation turns its scalar adds into v_pk_add_f32 + v_mov pairs, which cost more issue slots beside MFMAs, not fewer.
+EXTRA_FLAGS = {"attention_bf3.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target: str, deps) -> bool:
@@ -30,7 +33,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             jobs.append(cmd)

@@ -10,8 +10,10 @@
 // (global_load_lds_dwordx4, double-buffered, counted vmcnt), Q fragments sit in registers.
 // Both products are computed transposed exactly like attention.hip (S^T = K.Q^T, O^T += V^T.P^T), so the softmax
 // statistics are lane-local and the fp32 accumulators of S^T, after exp and the hi/lo split, ARE the B operands
-// of the second product.  LDS rows are 128 B; the 16-byte slot index is XOR-swizzled with (row & 7) on the source
-// address of the direct load and on the fragment read, so ds_read_b128 over 32 consecutive rows is <= 2-way.
+// of the second product.  LDS rows are 128 B; the 16-byte slot index is XOR-swizzled with ((row >> 1) & 7) on the source
+// address of the direct load and on the fragment read, so a ds_read_b128 over 32 consecutive rows is conflict-free (see faddr).
+#include <cstdlib>
+#include <type_traits>
 #include "conv_common.h"   // lds_read128 / lgkm_wait / static_for
 
 namespace pf {
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
   auto issue_piece = [&](int t, int stage, int j) {
     const int u = tid + j * NT;
     const int arr = u >> 9, row = (u & 511) >> 3;
-    const int src_slot = (u & 7) ^ (row & 7);     // swizzle on the SOURCE side; the LDS image stays lane-linear
+    const int src_slot = (u & 7) ^ ((row >> 1) & 7);     // swizzle on the SOURCE side; the LDS image stays lane-linear
     const __bf16* gp = (arr < 2) ? kbase + (size_t)(arr & 1) * MC + (size_t)(t * KT + row) * C + src_slot * 8
                                  : vbase + (size_t)(arr & 1) * MC + (size_t)row * L + t * KT + src_slot * 8;
     __bf16* lp = sm + stage * STAGE + (j * NT + wave * 64) * 8;   // wave-uniform; the hardware adds lane*16 B
@@ -107,11 +109,15 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
   const int ntile = L / KT;            // even: L is a multiple of 128
   const int r31 = lane & 31;
   // LDS byte address of this lane's fragment row inside an 8 KB array, one per K-step pair: row = r31 (+32 per fragment,
-  // an immediate), 16-byte slot = (2 sp + g) ^ (row & 7).  K and V^T fragments share the formula (row = key or channel).
+  // an immediate), 16-byte slot = (2 sp + g) ^ ((row >> 1) & 7).  K and V^T fragments share the formula (row = key or channel).
+  // The key is row >> 1, not row: the LDS of this part has 64 banks (256 B), a ds_read_b128 is served sixteen lanes at a time, and
+  // sixteen consecutive 128-byte rows must spread over both halves of the 256 bytes AND all eight slots of each half - with (row & 7)
+  // rows r and r + 8 met in the same banks (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE; tools/micro/lds_b128.hip: 32 against
+  // 24.8 cycles per wave-instruction with four waves reading).
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) __bf16*)sm;
   unsigned faddr[4];
 #pragma unroll
-  for (int sp = 0; sp < 4; ++sp) faddr[sp] = lds0 + r31 * 128 + (((2 * sp + g) ^ (r31 & 7)) * 16);
+  for (int sp = 0; sp < 4; ++sp) faddr[sp] = lds0 + r31 * 128 + (((2 * sp + g) ^ ((r31 >> 1) & 7)) * 16);
   constexpr int STAGE_B = STAGE * 2, ARR_B = KT * DH * 2;
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
@@ -255,19 +261,349 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
     }
 }
 
+// ---- 256-query form: two query fragments per wave, softmax software-pipelined across tiles --------------------------------------
+// With one 32-query fragment per wave every wave reads the whole K / V^T tile for 48 MFMAs; here a fragment read feeds two query
+// fragments (half the LDS bytes per MFMA, half the workgroups streaming tiles).  That costs the second wave per SIMD (one wave owns
+// the whole 512-register file: O^T and S^T accumulators in the accumulator file, scores / probabilities in arch VGPRs), so nothing
+// covers the softmax any more - it is pipelined by hand instead: while the matrix pipe computes S(t+1) the vector ALU turns the
+// scores of tile t into probabilities (fma, exp2, row sums) and splits the first key block, while it computes O += V.P(t) the ALU
+// splits the other key blocks, moves the raw scores of S(t+1) out of the accumulator file and reduces their row maxima.  The
+// reference exponent of a row moves lazily (see TAU), so the accumulators are rescaled a few times per row, in a wave-uniform
+// branch at the head of an iteration where no register load is in flight.
+// Measured (B = 16, 4 heads, L = 1024: 256 workgroups): 57 -> 51 us per launch in a back-to-back loop, 70 -> 64 us inside the
+// step (kernel trace); the whole step does not move (+-0.3 %), the part runs power-managed (sclk ~2.0 GHz in the step, ~1.65 GHz
+// in a loop of this kernel alone) and a kernel that idles less clocks lower.  Cycle stamps: an S region (12 MFMAs) takes ~500 cycles,
+// a PV region 850-1200 against 384 at pipe speed - the open problem of this kernel.
+template <int RING>
+__global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
+  constexpr int NWAVES = 4, QF = 2, DH = 64, KT = 64, NT = NWAVES * 64, NP = 2048 / NT;
+  constexpr int STAGE = 4 * KT * DH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);   // [RING stages][K hi, K lo, V^T hi, V^T lo][64 rows][64]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqt = p.L / (NWAVES * 32 * QF);
+  int lid;
+  {   // XCD-aware order: all query tiles of a (batch, head) on one XCD's L2 (see attn_bf3_kernel)
+    const int orig = blockIdx.x, nwg = gridDim.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+  }
+  const int bh = fdiv(lid, p.d_nqt), qt = lid - bh * nqt;
+  const int b = fdiv(bh, p.d_h), h = bh - b * p.H;
+#ifdef PF_TRACE
+  const bool trace_on = tid == 0 && qt == 1 && h == 1 && b == 1;
+  int tslot = 0;
+#endif
+  const int g = lane >> 5;
+  const int C = p.H * DH, L = p.L;
+  const size_t MC = (size_t)p.B * L * C;
+  const int qi = qt * (NWAVES * 32 * QF) + wave * (32 * QF) + (lane & 31);   // + 32 qf
+
+  bf16x8 qh[QF][4], ql[QF][4];
+#pragma unroll
+  for (int qf = 0; qf < QF; ++qf) {
+    const __bf16* qp = p.planes + ((size_t)b * L + qi + 32 * qf) * C + h * DH + 8 * g;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qh[qf][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+      ql[qf][s] = *reinterpret_cast<const bf16x8*>(qp + MC + 16 * s);
+    }
+  }
+
+  const __bf16* kbase = p.planes + 2 * MC + (size_t)b * L * C + h * DH;
+  const __bf16* vbase = p.planes + 4 * MC + ((size_t)b * p.H + h) * DH * L;
+  // piece j of a tile (unit u = tid + 256 j): array j/2 (K hi, K lo, V^T hi, V^T lo), row tid/8 + 32 (j & 1), 16-byte slot
+  // (tid & 7) ^ ((row >> 1) & 7) - the same slot for every j.  The source address is a wave-uniform base (tile, array, row half: scalar ALU)
+  // plus one 32-bit per-thread offset per operand, so an issue costs no vector instructions and no address registers.
+  const unsigned rsl = (unsigned)(tid >> 3), ssl = (unsigned)((tid & 7) ^ ((tid >> 4) & 7)) * 8u;
+  const unsigned koff = (rsl * (unsigned)C + ssl) * 2u, voff = (rsl * (unsigned)L + ssl) * 2u;   // bytes
+  auto issue_piece = [&](int t, int stage, int j) {
+    const int arr = j >> 1, half = j & 1;
+    const char* ub = (arr < 2) ? reinterpret_cast<const char*>(kbase + (size_t)(arr & 1) * MC + (size_t)(t * KT + 32 * half) * C)
+                               : reinterpret_cast<const char*>(vbase + (size_t)(arr & 1) * MC + (size_t)(32 * half) * L + t * KT);
+    const char* gp = ub + ((arr < 2) ? koff : voff);
+    __bf16* lp = sm + stage * STAGE + (j * NT + wave * 64) * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                     (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+  };
+  auto issue_tile = [&](int t, int stage) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) issue_piece(t, stage, j);
+  };
+
+  f32x16 oacc[QF][2];       // O^T accumulators (accumulator file)
+  f32x16 sacc[QF][2];       // S^T accumulators of the tile being multiplied (accumulator file)
+  f32x16 pv[QF][2];         // arch VGPRs: scores of the tile in the softmax - raw, then probabilities; a key block's sixteen registers
+                            // are refilled with the next tile's raw scores as soon as its probabilities have been split
+  float m_run[QF], l_run[QF], alpha[QF], mx[QF];
+  constexpr float TAU = 6.f;   // the reference exponent of a row only moves when its maximum grew by more than 2^TAU (see below)
+#pragma unroll
+  for (int qf = 0; qf < QF; ++qf) {
+    m_run[qf] = -INFINITY; l_run[qf] = 0.f; alpha[qf] = 0.f; mx[qf] = -INFINITY;
+#pragma unroll
+    for (int df = 0; df < 2; ++df)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qf][df][r] = 0.f;
+  }
+
+  const int ntile = L / KT;
+  const int r31 = lane & 31;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) __bf16*)sm;
+  unsigned faddr[4];
+#pragma unroll
+  for (int sp = 0; sp < 4; ++sp) faddr[sp] = lds0 + r31 * 128 + (((2 * sp + g) ^ ((r31 >> 1) & 7)) * 16);
+  constexpr int STAGE_B = STAGE * 2, ARR_B = KT * DH * 2;
+  const float c2 = p.scale * 1.44269504088896340736f;
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define IC(N) std::integral_constant<int, (N)>{}
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x8 fh[2][2], fl[2][2];      // [buffer][fragment]
+  u32x4 phw[2][QF], plw[2][QF];   // probabilities of one key block as packed bf16 pairs, hi and lo [buffer][query fragment]
+  float th0[8], th1[8];           // hi/lo split in flight (one slot per item of a key block)
+
+  // ---- the static schedule of one iteration ------------------------------------------------------------------------------------
+  // 96 gaps = 96 MFMAs: gaps 0..47 are S(t+1) (region r = gap / 12 is K step r), gaps 48..95 are PV(t) (region 4 + kb).  Inside a
+  // region MFMA m is product m / 4 of the split (a_lo.b_hi, a_hi.b_lo, a_hi.b_hi) on accumulator (qf, kf) = ((m >> 1) & 1, m & 1).
+  // Every gap carries one MFMA and its share of the ALU items below, fenced from its neighbours; a measured lone wave hides about
+  // four single-issue instructions per MFMA and pays ~3 cycles for each further one (tools/micro/mfma_war.hip), a v_accvgpr_read of
+  // an idle accumulator costs what a v_mov costs (tools/micro/mfma_acc.hip), four ds_read_b128 or two LDS-DMA issues back to back
+  // stall the wave for 50-150 cycles each - hence one LDS read per gap and an even ~5.8 instructions per gap:
+  //  * exp item i (0..63: key block i / 16, query fragment (i >> 3) & 1, key i & 7), three dependent instructions in three
+  //    consecutive gaps from gap 3 i / 4: fma (s c2 - m), exp2, row-sum add;
+  //  * split item (block b, j = 4 qf + pair): cvt_pk | shift + mask | two subtractions | cvt_pk in four consecutive gaps.  Block 0
+  //    from gap 16 + 4 j (its exponentials are done by gap 14), block b >= 1 from gap 48 + 12 (b - 1) + j - inside the PV region
+  //    before the one that multiplies it;
+  //  * copy pair c (0..31: block c / 8): two raw scores of S(t+1) from the accumulator file into the registers of a key block whose
+  //    probabilities have been split, one v_max3 - pairs 0-4 in PV region 0, 5-9 in region 1, 10-14 in region 2, the rest in region 3;
+  //  * the four fragment reads for the next region in gaps 4..7 of a region, the tile's eight direct-to-LDS pieces in gap 9.
+  auto exp_stage = [&](auto ic, auto stc) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value, ST = decltype(stc)::value, blk = i >> 4, qf = (i >> 3) & 1, e = 8 * (blk & 1) + (i & 7);
+    const float x = pv[qf][blk >> 1][e];
+    if constexpr (ST == 0) pv[qf][blk >> 1][e] = __builtin_fmaf(x, c2, -m_run[qf]);
+    else if constexpr (ST == 1) pv[qf][blk >> 1][e] = __builtin_amdgcn_exp2f(x);
+    else l_run[qf] += x;
+  };
+  auto split_stage = [&](auto blkc, auto jc, auto stc) __attribute__((always_inline)) {
+    constexpr int BLK = decltype(blkc)::value, j8 = decltype(jc)::value, ST = decltype(stc)::value, BUF = BLK & 1;
+    constexpr int qf = j8 >> 2, j = j8 & 3, e = 8 * (BLK & 1) + 2 * j;
+    const float v0 = pv[qf][BLK >> 1][e], v1 = pv[qf][BLK >> 1][e + 1];
+    if constexpr (ST == 0) {
+      const f32x2 v = {v0, v1};
+      phw[BUF][qf][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // hi = RNE bf16 pair (key 2j in the low half)
+    } else if constexpr (ST == 1) {   // the float values of hi, rebuilt from the packed word
+      th0[j8] = __uint_as_float(phw[BUF][qf][j] << 16);
+      th1[j8] = __uint_as_float(phw[BUF][qf][j] & 0xffff0000u);
+    } else if constexpr (ST == 2) {
+      th0[j8] = v0 - th0[j8];
+      th1[j8] = v1 - th1[j8];
+    } else {
+      const f32x2 r = {th0[j8], th1[j8]};
+      plw[BUF][qf][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    }
+  };
+  auto copy_pair = [&](auto cc) __attribute__((always_inline)) {
+    constexpr int c = decltype(cc)::value, blk = c >> 3, qf = (c >> 2) & 1, e = 8 * (blk & 1) + 2 * (c & 3);
+    const float r0 = sacc[qf][blk >> 1][e], r1 = sacc[qf][blk >> 1][e + 1];
+    pv[qf][blk >> 1][e] = r0;
+    pv[qf][blk >> 1][e + 1] = r1;
+    mx[qf] = fmaxf(fmaxf(mx[qf], r0), r1);
+  };
+  // ALU items of gap G
+  auto gap_items = [&](auto gc, auto dosc, auto dopvc) __attribute__((always_inline)) {
+    constexpr int G = decltype(gc)::value;
+    constexpr bool DO_S = decltype(dosc)::value, DO_PV = decltype(dopvc)::value;
+    if constexpr (DO_PV) {
+      static_for<0, 64>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, g0 = (3 * i) >> 2;
+        if constexpr (G >= g0 && G <= g0 + 2) exp_stage(ic, IC(G - g0));
+      });
+      static_for<0, 8>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (G >= 16 + 4 * j && G <= 19 + 4 * j) split_stage(IC(0), jc, IC(G - 16 - 4 * j));
+        static_for<1, 4>([&](auto bc) {
+          constexpr int b = decltype(bc)::value, g0 = 48 + 12 * (b - 1) + j;
+          if constexpr (G >= g0 && G <= g0 + 3) split_stage(bc, jc, IC(G - g0));
+        });
+      });
+    }
+    if constexpr (DO_S) {
+      static_for<0, 32>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        // pairs 0..14: five per PV region 0..2 at gaps 1, 3, 5, 8, 10 of the region; pairs 15..31: PV region 3, gap (c - 15) * 12 / 17
+        constexpr int five[5] = {1, 3, 5, 8, 10};
+        constexpr int g = c < 15 ? 48 + 12 * (c / 5) + five[c % 5] : 84 + ((c - 15) * 12) / 17;
+        if constexpr (G == g) copy_pair(cc);
+      });
+    }
+  };
+
+  // One iteration: S(t+1) [DO_S] beside the exponentials of tile t, then PV(t) [DO_PV] beside the hi/lo splits of tile t and the
+  // raw scores + row maxima of S(t+1).  ST1 = LDS stage of tile t+1, ST0 = stage of tile t.
+  auto iteration = [&](auto st1c, auto dosc, auto dopvc, int t) __attribute__((always_inline)) {
+    constexpr int ST1 = decltype(st1c)::value, ST0 = (ST1 + RING - 1) % RING;
+    constexpr bool DO_S = decltype(dosc)::value, DO_PV = decltype(dopvc)::value;
+    constexpr int SB1 = ST1 * STAGE_B, SB0 = ST0 * STAGE_B;
+    TRA();
+    if constexpr (DO_S) {
+      // tile t+1 has landed once only tile t+2 of this thread is outstanding; the barrier publishes it and frees the stage of tile t-1
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 3) * NP) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    TRA();
+    if constexpr (DO_PV) {
+      // lazy rescale: rows whose reference exponent moved (alpha != 1) - rare after the first tiles; no register load is in flight here
+      bool moved = false;
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf) moved |= alpha[qf] != 1.0f;
+      if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+#pragma unroll
+        for (int qf = 0; qf < QF; ++qf) {
+          l_run[qf] *= alpha[qf];
+#pragma unroll
+          for (int df = 0; df < 2; ++df) oacc[qf][df] = oacc[qf][df] * alpha[qf];
+        }
+      }
+    }
+    if constexpr (DO_S) {
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf) mx[qf] = -INFINITY;
+    }
+    const int tn = min(t + RING - 1, ntile - 1);
+    constexpr int STN = (ST1 + RING - 2) % RING;   // stage of tile t-1 == stage of tile t+RING-1
+
+    // fragments of region 0 (K step 0 of tile t+1, or - last iteration - nothing: region 3 reads V^T block 0 as always)
+    if constexpr (DO_S) {
+      fh[0][0] = lds_read128<SB1>(faddr[0]);          fl[0][0] = lds_read128<SB1 + ARR_B>(faddr[0]);
+      fh[0][1] = lds_read128<SB1 + 4096>(faddr[0]);   fl[0][1] = lds_read128<SB1 + ARR_B + 4096>(faddr[0]);
+    }
+    static_for<0, 96>([&](auto gc) {
+      constexpr int G = decltype(gc)::value, R = G / 12, m = G % 12, bb = R & 1, prod = m >> 2, qf = (m >> 1) & 1, kf = m & 1;
+      constexpr bool S_REG = R < 4;
+      if constexpr (m == 0) {   // region head: this region's fragments (read in gaps 4..7 of the previous region) have landed
+        if constexpr (G == 48) TRA();
+        SB(); lgkm_wait<0>(); SB();
+      }
+      // ---- the MFMA ----
+      if constexpr (S_REG && DO_S) {
+        constexpr int sp = R;
+        const bf16x8 a = prod == 0 ? fl[bb][kf] : fh[bb][kf];
+        const bf16x8 bq = prod == 1 ? ql[qf][sp] : qh[qf][sp];
+        if constexpr (sp == 0 && prod == 0) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          sacc[qf][kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, z, 0, 0, 0);
+        } else {
+          sacc[qf][kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, sacc[qf][kf], 0, 0, 0);
+        }
+      }
+      if constexpr (!S_REG && DO_PV) {
+        const bf16x8 a = prod == 0 ? fl[bb][kf] : fh[bb][kf];   // kf = V^T channel fragment here
+        const bf16x8 bp = __builtin_bit_cast(bf16x8, prod == 1 ? plw[bb][qf] : phw[bb][qf]);
+        oacc[qf][kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp, oacc[qf][kf], 0, 0, 0);
+      }
+      // ---- one fragment read for the next region (gaps 4..7), into the buffer the previous region used ----
+      if constexpr (m >= 4 && m < 8) {
+        constexpr int f = m - 4, NR = R + 1;   // f: 0 hi frag 0, 1 lo frag 0, 2 hi frag 1, 3 lo frag 1
+        constexpr int FO = (f >> 1) * 4096, PL = f & 1;
+        if constexpr (NR < 4) {   // K step NR of tile t+1
+          if constexpr (DO_S) {
+            const bf16x8 v = lds_read128<SB1 + PL * ARR_B + FO>(faddr[NR]);
+            if constexpr (PL == 0) fh[bb ^ 1][f >> 1] = v; else fl[bb ^ 1][f >> 1] = v;
+          }
+        } else if constexpr (NR < 8) {   // V^T key block NR - 4 of tile t
+          if constexpr (DO_PV) {
+            const bf16x8 v = lds_read128<SB0 + (2 + PL) * ARR_B + FO>(faddr[NR - 4]);
+            if constexpr (PL == 0) fh[bb ^ 1][f >> 1] = v; else fl[bb ^ 1][f >> 1] = v;
+          }
+        }
+      }
+      if constexpr (m == 9 && DO_S) issue_piece(tn, STN, R);
+      gap_items(gc, dosc, dopvc);
+      SB();
+    });
+    if constexpr (DO_S) {
+#pragma unroll
+      for (int qf = 0; qf < QF; ++qf) {
+        const unsigned u = __float_as_uint(mx[qf] * c2);   // c2 > 0: the maximum of the scaled scores
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        // p = exp2(s - m) only needs SOME common m per row that keeps p in range: m follows the row maximum when that grew by more
+        // than 2^TAU (p <= 64 otherwise - harmless in fp32 and in the hi/lo split), so the accumulators are rescaled a few times per
+        // row instead of once per tile
+        const float mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        const float m_new = mt > m_run[qf] + TAU ? mt : m_run[qf];
+        alpha[qf] = __builtin_amdgcn_exp2f(m_run[qf] - m_new);   // first tile: exp2(-inf) = 0 on zero accumulators
+        m_run[qf] = m_new;
+      }
+    }
+  };
+  using T = std::true_type; using Fz = std::false_type;
+  TRA();
+  // iteration t issues tile t+RING-1 and needs tile t+1: RING-3 tiles stay in flight across its barrier
+#pragma unroll
+  for (int d = 0; d < RING - 2; ++d) issue_tile(min(d, ntile - 1), d);
+  iteration(std::integral_constant<int, 0>{}, T{}, Fz{}, -1);
+  for (int t = 0; t + RING < ntile; t += RING)   // ntile is a multiple of RING (launcher)
+    static_for<0, RING>([&](auto st) {
+      constexpr int S0 = decltype(st)::value;
+      iteration(std::integral_constant<int, (S0 + 1) % RING>{}, T{}, T{}, t + S0);
+    });
+  static_for<0, RING>([&](auto st) {   // last RING tiles: the final one has no S(t+1)
+    constexpr int S0 = decltype(st)::value;
+    if constexpr (S0 < RING - 1) iteration(std::integral_constant<int, (S0 + 1) % RING>{}, T{}, T{}, ntile - RING + S0);
+    else iteration(std::integral_constant<int, (S0 + 1) % RING>{}, Fz{}, T{}, ntile - 1);
+  });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail prefetch
+#undef IC
+#undef SB
+
+#pragma unroll
+  for (int qf = 0; qf < QF; ++qf) {
+    const float inv = 1.0f / (l_run[qf] + __shfl_xor(l_run[qf], 32));
+    const int qq = qi + 32 * qf;
+    float* op = p.o + ((size_t)b * L + qq) * p.ldo + h * DH;
+#pragma unroll
+    for (int df = 0; df < 2; ++df)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f32x4 v;
+        v[0] = oacc[qf][df][4 * c + 0] * inv; v[1] = oacc[qf][df][4 * c + 1] * inv;
+        v[2] = oacc[qf][df][4 * c + 2] * inv; v[3] = oacc[qf][df][4 * c + 3] * inv;
+        if (p.o_planes) {
+          bf16x4 h4 = __builtin_convertvector(v, bf16x4);
+          const f32x4 hf = __builtin_convertvector(h4, f32x4);
+          bf16x4 l4 = __builtin_convertvector(v - hf, bf16x4);
+          __bf16* pp = p.o_planes + ((size_t)b * L + qq) * C + h * DH + df * 32 + 8 * c + 4 * g;
+          *reinterpret_cast<bf16x4*>(pp) = h4;
+          *reinterpret_cast<bf16x4*>(pp + MC) = l4;
+        } else {
+          *reinterpret_cast<f32x4*>(op + df * 32 + 8 * c + 4 * g) = v;
+        }
+      }
+  }
+}
+
 int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, hipStream_t stream) {
   PF_REQUIRE(planes && (o || o_planes) && batch > 0 && n_heads > 0 && l > 0 && l % 128 == 0, "attention_bf3: L must be a positive multiple of 128");
+  // the 256-query form where it still gives most CUs a workgroup (PF_ATTN_WIDE = 0 / 1 pins the form: tests, A/B runs)
+  const char* force = getenv("PF_ATTN_WIDE");
+  const bool wide = l % 256 == 0 && (force ? force[0] == '1' : (l / 256) * n_heads * batch >= 192);
   AttnP3 p{static_cast<const __bf16*>(planes), o, ldo, static_cast<__bf16*>(o_planes), batch, n_heads, l, 0.125f,
-           make_fastdiv(l / 128), make_fastdiv(n_heads)};
+           make_fastdiv(wide ? l / 256 : l / 128), make_fastdiv(n_heads)};
   // (an 8-wave / 256-query form - half the K/V^T tile traffic per query - was measured and lost: its waves run S / softmax / PV in
   // lockstep behind one barrier, so the matrix pipe idles during every softmax, while two independent 4-wave workgroups per CU drift
   // apart and fill each other's gaps)
   static bool done = false;
   if (!done) {
     PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf3_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768));
+    PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf3_wide_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
     done = true;
   }
-  hipLaunchKernelGGL((attn_bf3_kernel<4, 2>), dim3((l / 128) * n_heads * batch), dim3(256), 2 * 32768, stream, p);
+  if (wide) hipLaunchKernelGGL((attn_bf3_wide_kernel<4>), dim3((l / 256) * n_heads * batch), dim3(256), 4 * 32768, stream, p);
+  else hipLaunchKernelGGL((attn_bf3_kernel<4, 2>), dim3((l / 128) * n_heads * batch), dim3(256), 2 * 32768, stream, p);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }

@@ -165,9 +165,15 @@ def test_split_k_small_m_layers(lib, B, H, W, c0, c1, cout):
     assert (tot[..., 0] - o.sum((1, 2))).abs().max() < 1e-2 and (tot[..., 1] - (o * o).sum((1, 2))).abs().max() < 1e-2
 
 
-@pytest.mark.parametrize("B,L,H", [(2, 1024, 4), (3, 256, 4), (1, 128, 2)])
-def test_qkv_planes_and_bf16x3_attention(lib, B, L, H):
-    """q|k|v projection (LayerNorm prologue) written as pre-split bf16 hi/lo planes, consumed by the bf16x3 attention."""
+@pytest.mark.parametrize("B,L,H,wide", [(2, 1024, 4, "0"), (3, 256, 4, "0"), (1, 128, 2, "0"), (2, 1024, 4, "1"), (3, 256, 4, "1"),
+                                        (16, 1024, 4, None)])
+def test_qkv_planes_and_bf16x3_attention(lib, B, L, H, wide, monkeypatch):
+    """q|k|v projection (LayerNorm prologue) written as pre-split bf16 hi/lo planes, consumed by the bf16x3 attention - in its
+    128-query form, in the 256-query form (two query fragments per wave), and at the bench shape with the launcher's own choice."""
+    if wide is None:
+        monkeypatch.delenv("PF_ATTN_WIDE", raising=False)
+    else:
+        monkeypatch.setenv("PF_ATTN_WIDE", wide)
     c = H * 64
     x = rnd((B, L, c), 81) * 1.3 + 0.2
     gamma, beta = 1 + 0.1 * rnd((c,), 82), 0.1 * rnd((c,), 83)

@@ -16,7 +16,9 @@ patched = os.path.join(CSRC, f"_exp_{name}_{f}")   # must sit next to its header
 open(patched, "w").write(src)
 obj = os.path.join(out_dir, f"{name}.o")
 try:
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-c", patched, "-o", obj])
+    sys.path.insert(0, REPO)
+    from polyffusion_amd.build import EXTRA_FLAGS
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function"] + EXTRA_FLAGS.get(f, []) + os.environ.get("PF_EXP_DEFS", "").split() + ["-c", patched, "-o", obj])
 finally:
     os.remove(patched)
 objs = [os.path.join(CSRC, o) for o in sorted(os.listdir(CSRC)) if o.endswith(".o") and o != f.replace(".hip", ".o")]

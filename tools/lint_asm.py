@@ -28,6 +28,8 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SOURCES = ["conv_bf16x3.hip", "gemm_planes_bf3.hip", "attention_bf3.hip", "mlp_fused_bf3.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+sys.path.insert(0, REPO)
+from polyffusion_amd.build import EXTRA_FLAGS  # noqa: E402  (the lint must read the assembly the library is built from)
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 
@@ -169,7 +171,8 @@ def compile_to_asm() -> list:
         out = os.path.join(out_dir, src.replace(".hip", ".s"))
         outs.append(out)
         procs.append(subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                                       "-Wno-unused-command-line-argument", os.path.join(REPO, "polyffusion_amd", "csrc", src), "-o", out]))
+                                       "-Wno-unused-command-line-argument"] + EXTRA_FLAGS.get(src, []) +
+                                      [os.path.join(REPO, "polyffusion_amd", "csrc", src), "-o", out]))
     for p in procs:
         if p.wait() != 0:
             raise SystemExit("hipcc failed")

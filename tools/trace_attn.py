@@ -25,8 +25,11 @@ a = np.array(buf[:], dtype=np.int64); a = a[a > 0]
 d = np.diff(a)
 print("stamps", len(a), "total", a[-1] - a[0])
 body = d[1:]
-n = len(body) // 5 * 5
-t = body[:n].reshape(-1, 5)
-print("per tile [wait, barrier, S phase (+next tile's glds), softmax, PV + loop]")
+wide = os.environ.get("PF_ATTN_WIDE") == "1"   # the 256-query form stamps an iteration three times
+k = int(os.environ.get("PF_TRACE_STAMPS", "3")) if wide else 5
+n = len(body) // k * k
+t = body[:n].reshape(-1, k)
+print("per iteration [wait + barrier, rescale check + S(t+1) beside the exponentials, PV(t) beside splits / maxima]" if wide else
+      "per tile [wait, barrier, S phase (+next tile's glds), softmax, PV + loop]")
 for r in t[:6]: print("   ", r.tolist(), int(r.sum()))
 print("mean", t.mean(0).round(0).tolist(), round(float(t.sum(1).mean())))
