@@ -50,6 +50,10 @@ class DiffusionSampler:
         # to the eager loop.  Used only with the on-device noise generator (an injected noise_fn is host code).
         self.graph = bool(graph)
         self._dev_cache = {}
+        # captured steps, kept across paint() calls (the autoregressive schedule calls paint() 2B-1 times with the same shapes):
+        # key = everything that shapes the captured launch sequence, value = the graph + the static buffers its nodes point at
+        self._graphs = {}
+        self.graph_captures = 0
 
     def _step_state(self, device) -> torch.Tensor:
         key = ("state", str(device))
@@ -59,6 +63,50 @@ class DiffusionSampler:
 
     def _set_state(self, st: torch.Tensor, index: int):
         _lib.check(self._lib.pf_step_state_set(st.data_ptr(), int(index), int(self._draws), _lib.current_stream()), "pf_step_state_set")
+
+    _MAX_GRAPHS = 4
+
+    def _graph_token(self):
+        """What a captured step depends on besides its own buffers: the UNet's workspace and weight blob (addresses are baked
+        into the graph nodes; the workspace is re-allocated when a larger batch comes along) and the arithmetic mode."""
+        m = self.model.eps_model
+        ws = getattr(m, "_ws", None)
+        blob = getattr(m, "_blob_dev", None)
+        return (0 if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), 0 if blob is None else blob.data_ptr(),
+                getattr(m, "precision", None))
+
+    def _graph_for(self, key, inputs, make_body, reset):
+        """The captured step for `key`, with `inputs` (name -> tensor or None) copied into its static buffers.  A cached entry is
+        dropped when the UNet's workspace / weights / mode changed since its capture.  `make_body(bufs)` returns the step closure
+        over the static buffers, `reset()` re-arms the device step state (called after every buffer refresh).  Returns the entry
+        {"g": graph, "bufs": {...}}."""
+        ent = self._graphs.get(key)
+        if ent is not None and ent["token"] != self._graph_token():
+            del self._graphs[key]
+            ent = None
+        if ent is None:
+            bufs = {k: (None if v is None else v.clone()) for k, v in inputs.items()}
+
+            def restore():
+                bufs["x"].copy_(inputs["x"])
+                reset()
+
+            reset()
+            g = self._capture(make_body(bufs), restore)
+            self.graph_captures += 1
+            while len(self._graphs) >= self._MAX_GRAPHS:
+                self._graphs.pop(next(iter(self._graphs)))
+            ent = self._graphs[key] = {"g": g, "bufs": bufs, "token": self._graph_token()}   # token AFTER the warm-up sized the workspace
+        else:
+            for k, v in inputs.items():
+                if v is not None:
+                    ent["bufs"][k].copy_(v)
+            reset()
+        return ent
+
+    @staticmethod
+    def _shape_key(**tensors):
+        return tuple((k, None if v is None else (tuple(v.shape), str(v.dtype))) for k, v in sorted(tensors.items()))
 
     def _capture(self, body, restore):
         """Warm `body` up once on a side stream (sizes the workspace, primes the allocator), undo its effect with `restore`,
@@ -139,31 +187,32 @@ class SDFSampler(DiffusionSampler):
         """Steps t_start .. 1 as replays of one captured step; returns x_1 (the caller runs step 0, which draws no noise)."""
         lib, dev, B, n = self._lib, x.device, x.shape[0], x.numel()
         table, st = self._coef_table(dev), self._step_state(dev)
-        xb = x.clone()
-        tb = torch.empty(B, dtype=torch.long, device=dev)
-        nq = torch.empty_like(xb) if orig is not None else None
-        npz = torch.empty_like(xb)
         off = self.sample_offset * (n // B)
         ndraw = 2 if orig is not None else 1
+        inputs = dict(x=x, cond=cond, orig=orig, mask=mask, uncond_cond=uncond_cond, cond_concat=cond_concat)
 
-        def body():
-            stream = _lib.current_stream()
-            _lib.check(lib.pf_step_begin(st.data_ptr(), None, tb.data_ptr(), B, stream), "pf_step_begin")
-            if orig is not None:   # draw order of the reference: known-region noise first, then the p_sample noise
-                _lib.check(lib.pf_randn_dev(nq.data_ptr(), n, self.seed, st.data_ptr(), 0, off, stream), "pf_randn_dev")
-            xin = xb if cond_concat is None else torch.cat([xb, cond_concat], dim=1)
-            e_t = self.get_eps(xin, tb, cond, uncond_scale=uncond_scale, uncond_cond=uncond_cond)
-            _lib.check(lib.pf_randn_dev(npz.data_ptr(), n, self.seed, st.data_ptr(), ndraw - 1, off, stream), "pf_randn_dev")
-            _lib.check(lib.pf_ddpm_step_dev(xb.data_ptr(), e_t.data_ptr(), npz.data_ptr(), _lib.ptr(nq), _lib.ptr(orig), _lib.ptr(mask),
-                                            table.data_ptr(), st.data_ptr(), xb.data_ptr(), n, stream), "pf_ddpm_step_dev")
-            _lib.check(lib.pf_step_end(st.data_ptr(), ndraw, stream), "pf_step_end")
+        def make_body(bf):
+            xb, tb, npz = bf["x"], torch.empty(B, dtype=torch.long, device=dev), torch.empty_like(bf["x"])
+            nq = torch.empty_like(xb) if bf["orig"] is not None else None
+            bf["_keep"] = (tb, npz, nq)
 
-        def restore():
-            xb.copy_(x)
-            self._set_state(st, t_start)
+            def body():
+                stream = _lib.current_stream()
+                _lib.check(lib.pf_step_begin(st.data_ptr(), None, tb.data_ptr(), B, stream), "pf_step_begin")
+                if nq is not None:   # draw order of the reference: known-region noise first, then the p_sample noise
+                    _lib.check(lib.pf_randn_dev(nq.data_ptr(), n, self.seed, st.data_ptr(), 0, off, stream), "pf_randn_dev")
+                xin = xb if bf["cond_concat"] is None else torch.cat([xb, bf["cond_concat"]], dim=1)
+                e_t = self.get_eps(xin, tb, bf["cond"], uncond_scale=uncond_scale, uncond_cond=bf["uncond_cond"])
+                _lib.check(lib.pf_randn_dev(npz.data_ptr(), n, self.seed, st.data_ptr(), ndraw - 1, off, stream), "pf_randn_dev")
+                _lib.check(lib.pf_ddpm_step_dev(xb.data_ptr(), e_t.data_ptr(), npz.data_ptr(), _lib.ptr(nq), _lib.ptr(bf["orig"]),
+                                                _lib.ptr(bf["mask"]), table.data_ptr(), st.data_ptr(), xb.data_ptr(), n, stream),
+                           "pf_ddpm_step_dev")
+                _lib.check(lib.pf_step_end(st.data_ptr(), ndraw, stream), "pf_step_end")
+            return body
 
-        self._set_state(st, t_start)
-        g = self._capture(body, restore)
+        key = ("ddpm", str(dev), float(uncond_scale), self.seed, off) + self._shape_key(**inputs)
+        ent = self._graph_for(key, inputs, make_body, lambda: self._set_state(st, t_start))
+        g = ent["g"]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(t_start):
@@ -171,7 +220,7 @@ class SDFSampler(DiffusionSampler):
         e1.record()
         self.last_replay = (e0, e1, t_start)     # bench.py reads the per-step replay time from these events
         self._draws += ndraw * t_start
-        return xb
+        return ent["bufs"]["x"].clone()   # the static buffer is overwritten by the next paint() with these shapes
 
     def _coef(self, step: int) -> _lib.DdpmCoef:
         return _lib.DdpmCoef(float(self.sqrt_recip_alpha_bar[step]), float(self.sqrt_recip_m1_alpha_bar[step]),
@@ -293,28 +342,30 @@ class DDIMSampler(DiffusionSampler):
         (eta > 0) and draws one noise tensor, in the eager loop's draw order; otherwise (eta = 0) no step draws."""
         lib, dev, B, n = self._lib, x.device, x.shape[0], x.numel()
         (table, taus), st = self._coef_table(dev), self._step_state(dev)
-        xb = x.clone()
-        tb = torch.empty(B, dtype=torch.long, device=dev)
-        nz = torch.empty_like(xb) if noisy else None
         off = self.sample_offset * (n // B)
+        inputs = dict(x=x, cond=cond, orig=orig, mask=mask, orig_noise=orig_noise, uncond_cond=uncond_cond, cond_concat=cond_concat)
 
-        def body():
-            stream = _lib.current_stream()
-            _lib.check(lib.pf_step_begin(st.data_ptr(), taus.data_ptr(), tb.data_ptr(), B, stream), "pf_step_begin")
-            xin = xb if cond_concat is None else torch.cat([xb, cond_concat], dim=1)
-            e_t = self.get_eps(xin, tb, cond, uncond_scale=uncond_scale, uncond_cond=uncond_cond)
-            if noisy:
-                _lib.check(lib.pf_randn_dev(nz.data_ptr(), n, self.seed, st.data_ptr(), 0, off, stream), "pf_randn_dev")
-            _lib.check(lib.pf_ddim_step_dev(xb.data_ptr(), e_t.data_ptr(), _lib.ptr(nz), _lib.ptr(orig), _lib.ptr(orig_noise), _lib.ptr(mask),
-                                            table.data_ptr(), st.data_ptr(), xb.data_ptr(), n, stream), "pf_ddim_step_dev")
-            _lib.check(lib.pf_step_end(st.data_ptr(), 1 if noisy else 0, stream), "pf_step_end")
+        def make_body(bf):
+            xb, tb = bf["x"], torch.empty(B, dtype=torch.long, device=dev)
+            nz = torch.empty_like(xb) if noisy else None
+            bf["_keep"] = (tb, nz)
 
-        def restore():
-            xb.copy_(x)
-            self._set_state(st, t_start)
+            def body():
+                stream = _lib.current_stream()
+                _lib.check(lib.pf_step_begin(st.data_ptr(), taus.data_ptr(), tb.data_ptr(), B, stream), "pf_step_begin")
+                xin = xb if bf["cond_concat"] is None else torch.cat([xb, bf["cond_concat"]], dim=1)
+                e_t = self.get_eps(xin, tb, bf["cond"], uncond_scale=uncond_scale, uncond_cond=bf["uncond_cond"])
+                if noisy:
+                    _lib.check(lib.pf_randn_dev(nz.data_ptr(), n, self.seed, st.data_ptr(), 0, off, stream), "pf_randn_dev")
+                _lib.check(lib.pf_ddim_step_dev(xb.data_ptr(), e_t.data_ptr(), _lib.ptr(nz), _lib.ptr(bf["orig"]), _lib.ptr(bf["orig_noise"]),
+                                                _lib.ptr(bf["mask"]), table.data_ptr(), st.data_ptr(), xb.data_ptr(), n, stream),
+                           "pf_ddim_step_dev")
+                _lib.check(lib.pf_step_end(st.data_ptr(), 1 if noisy else 0, stream), "pf_step_end")
+            return body
 
-        self._set_state(st, t_start)
-        g = self._capture(body, restore)
+        key = ("ddim", str(dev), float(uncond_scale), self.seed, off, bool(noisy)) + self._shape_key(**inputs)
+        ent = self._graph_for(key, inputs, make_body, lambda: self._set_state(st, t_start))
+        g = ent["g"]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(t_start + 1):
@@ -323,7 +374,7 @@ class DDIMSampler(DiffusionSampler):
         self.last_replay = (e0, e1, t_start + 1)
         if noisy:
             self._draws += t_start + 1
-        return xb
+        return ent["bufs"]["x"].clone()   # the static buffer is overwritten by the next paint() with these shapes
 
     def _coef(self, index: int) -> _lib.DdimCoef:
         a, ap, sg = self.ddim_alpha[index], self.ddim_alpha_prev[index], self.ddim_sigma[index]

@@ -155,6 +155,47 @@ def test_graph_replay_is_bit_identical_to_the_eager_loop(ldm):
     for s in (s1, s2):
         s.out = [s.paint(s.randn((B, 2, 16, 16), cond.device), cond, 3, orig=orig, mask=mask) for _ in range(2)]
     assert torch.equal(s1.out[0], s2.out[0]) and torch.equal(s1.out[1], s2.out[1]) and not torch.equal(s1.out[0], s1.out[1])
+    assert s2.graph_captures == 1            # the second paint() replayed the step captured by the first
+
+
+def test_captured_step_is_reused_and_dropped_when_the_workspace_moves(ldm):
+    """The captured step is cached per (shapes, guidance scale, ...) across paint() calls - the autoregressive schedule calls paint()
+    2B-1 times - with the inputs copied into static buffers; a cached graph is dropped when the UNet's workspace was re-allocated
+    (a larger batch in between), because its nodes hold the old address.  Results stay bit-identical to the eager loop throughout,
+    and a returned image is not a view of the static buffer."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    B = 2
+    def inputs(k):
+        g = torch.Generator().manual_seed(k)
+        cond = torch.randn(B, 1, 32, generator=g).cuda()
+        orig = (torch.rand(B, 2, 16, 16, generator=g) < 0.1).float().cuda()
+        mask = torch.zeros(B, 2, 16, 16).cuda()
+        mask[:, :, : 4 + k] = 1
+        return cond, orig, mask
+    uc = -torch.ones(B, 1, 32).cuda()
+    eager, graph = DDIMSampler(ldm, 10, "uniform", 0.0, seed=9, graph=False), DDIMSampler(ldm, 10, "uniform", 0.0, seed=9, graph=True)
+    outs = {False: [], True: []}
+    for k in range(3):
+        cond, orig, mask = inputs(k)
+        for smp in (eager, graph):
+            x = smp.randn((B, 2, 16, 16), cond.device)
+            outs[smp.graph].append(smp.paint(smp.q_sample(orig, 5 + k, x), cond, 5 + k, orig=orig, mask=mask, orig_noise=x, uncond_scale=2.0,
+                                             uncond_cond=uc))
+        if k == 1:   # a larger batch re-allocates the UNet workspace
+            ldm(torch.zeros(B + 5, 2, 16, 16).cuda(), torch.zeros(B + 5, dtype=torch.long).cuda(), torch.zeros(B + 5, 1, 32).cuda())
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a, b)
+    assert not torch.equal(outs[True][0], outs[True][1])         # distinct results: no aliasing of the static buffer
+    assert graph.graph_captures == 2                              # captured once, re-captured after the workspace moved
+    # DDPM sampler, generate path without known region, then with one: two keys, one capture each
+    sd = SDFSampler(ldm, seed=3, graph=True)
+    se = SDFSampler(ldm, seed=3, graph=False)
+    cond, orig, mask = inputs(0)
+    for smp in (se, sd):
+        smp.res = [smp.paint(smp.randn((B, 2, 16, 16), cond.device), cond, 4),
+                   smp.paint(smp.randn((B, 2, 16, 16), cond.device), cond, 4, orig=orig, mask=mask),
+                   smp.paint(smp.randn((B, 2, 16, 16), cond.device), cond, 6)]
+    assert all(torch.equal(a, b) for a, b in zip(se.res, sd.res)) and sd.graph_captures == 2
 
 
 def test_comm_single_rank_broadcast():
