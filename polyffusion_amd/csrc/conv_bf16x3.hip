@@ -164,6 +164,10 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   u32x4 rw[NW];
   vsc = f32x4{1.f, 1.f, 1.f, 1.f}; vsh = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // With the GroupNorm finalize folded into this launch (p.gn_s0) the sample's scale / shift rows do not exist yet when loadA(0)
+  // runs: its two loads then fetch gamma / beta instead (same count of vector loads, values discarded) - nothing reads the rows,
+  // or pulls their cache lines into this CU's L1, before gn_fused_prologue has written them.
+  bool sc_ready = !((PRO == 1 || PRO == 2) && p.gn_s0);
   auto loadA = [&](int chunk) {
     const int cg = (cbeg + chunk) * BK;
     const float* src; int cs, co;
@@ -176,8 +180,10 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       else ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (PRO == 1 || PRO == 2) {
-      vsc = *reinterpret_cast<const f32x4*>(p.sc + (size_t)b * cin + cg + c4 * 4);
-      vsh = *reinterpret_cast<const f32x4*>(p.sh + (size_t)b * cin + cg + c4 * 4);
+      const float* scp = sc_ready ? p.sc + (size_t)b * cin : p.gn_gamma;
+      const float* shp = sc_ready ? p.sh + (size_t)b * cin : p.gn_beta;
+      vsc = *reinterpret_cast<const f32x4*>(scp + cg + c4 * 4);
+      vsh = *reinterpret_cast<const f32x4*>(shp + cg + c4 * 4);
     } else if (PRO == 3) {
       vsc = *reinterpret_cast<const f32x4*>(p.sc + cg + c4 * 4);
       vsh = *reinterpret_cast<const f32x4*>(p.sh + cg + c4 * 4);
@@ -270,8 +276,8 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
 
 
   // GroupNorm finalize folded into this launch (pf_conv_args.gn_*): runs while the first tile's loads are in flight - the halo /
-  // A-tile region of the LDS serves as its scratch and is only written by storeA afterwards - then re-reads chunk 0's scale/shift
-  // (loadA fetched them before they existed).
+  // A-tile region of the LDS serves as its scratch and is only written by storeA afterwards - then reads chunk 0's scale/shift
+  // (loadA(0) could not: the rows did not exist yet, see sc_ready).
   auto gnFused = [&]() {
     if constexpr (PRO == 1 || PRO == 2) {
       if (p.gn_s0) {
@@ -279,6 +285,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
         const int cg = cbeg * BK;
         vsc = *reinterpret_cast<const f32x4*>(p.sc + (size_t)b * cin + cg + c4 * 4);
         vsh = *reinterpret_cast<const f32x4*>(p.sh + (size_t)b * cin + cg + c4 * 4);
+        sc_ready = true;
       }
     }
   };
