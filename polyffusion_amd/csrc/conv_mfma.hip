@@ -20,6 +20,7 @@
 //   bf16 inputs - SURVEY.md 0).  Both LDS images are double buffered and the next tile's global
 //   loads are in flight (registers) while the current tile's MFMAs run; one barrier per tile.
 #include <stdlib.h>
+#include <cstdlib>
 #include "conv_common.h"
 
 namespace pf {
@@ -245,6 +246,10 @@ int conv_pick_tile(const pf_conv_args& a) {
   if (a.ks == 3 && a.stride == 2) return 2;
   // bf16x3 3x3: the wide tile + split-K beats twice as many narrow tiles; planes GEMMs (both operands direct-to-LDS): one 128x128 workgroup
   // per CU beats two 128x64 ones as soon as every CU gets one (measured at M = 16384, N = 256: K = 256 18.1 -> 16.1 us, K = 1024 37.5 -> 33.9 us)
+  // bf16x3 3x3 with 64 output channels in all (the 128x128 level): a 16x16-pixel tile when that still gives every CU two rounds of
+  // two workgroups - each wave then owns 128 pixels x 32 channels (four A fragments per weight fragment instead of two)
+  if (a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.stride == 1 && !a.ups && !a.ups_fold && npad == 64 && hout % 16 == 0 && wout % 16 == 0 &&
+      a.batch * (hout / 16) * (wout / 16) >= 1024 && !a.skip_w && a.c0 + a.c1 >= 128 && !getenv("PF_CONV_NO_T16")) return 3;
   const bool wide_at_256 = a.precision == PF_PREC_BF16X3 && (a.ks == 3 || a.a_planes);
   if (npad % 128 == 0 && mt128 * (npad / 128) >= (wide_at_256 ? 256 : 512)) return 0;
   if (mt128 * (npad / 64) >= 512) return 1;
@@ -253,7 +258,7 @@ int conv_pick_tile(const pf_conv_args& a) {
 void conv_tile_shape(const pf_conv_args& a, int tile, int* th, int* tw) {
   if (a.ks == 1) { *th = 1; *tw = tile == 2 ? 64 : 128; }
   else if (a.stride == 2) { *th = 4; *tw = 16; }
-  else { *th = tile == 2 ? 4 : 8; *tw = 16; }
+  else { *th = tile == 3 ? 16 : tile == 2 ? 4 : 8; *tw = 16; }
 }
 // split-K (bf16x3 3x3 only): layers whose tile grid cannot fill the chip (the 16x16 level at batch 16, most levels at
 // small batch) run ksplit K-slices per tile and a reduce kernel that also applies the epilogue
