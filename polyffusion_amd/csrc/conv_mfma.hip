@@ -250,6 +250,8 @@ int conv_pick_tile(const pf_conv_args& a) {
   // two workgroups - each wave then owns 128 pixels x 32 channels (four A fragments per weight fragment instead of two)
   if (a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.stride == 1 && !a.ups && !a.ups_fold && npad == 64 && hout % 16 == 0 && wout % 16 == 0 &&
       a.batch * (hout / 16) * (wout / 16) >= 1024 && !a.skip_w && a.c0 + a.c1 >= 128 && !getenv("PF_CONV_NO_T16")) return 3;
+  // (the same 16x16-pixel footprint for the 128-channel tile - 128 x 64 per wave, one workgroup per CU - measured worse at the 64x64
+  // level: r64_128_128 55.3 -> 57 us, the fused-skip form 79 -> 82, only the K = 3456 conv gained 2.5 %)
   const bool wide_at_256 = a.precision == PF_PREC_BF16X3 && (a.ks == 3 || a.a_planes);
   if (npad % 128 == 0 && mt128 * (npad / 128) >= (wide_at_256 ? 256 : 512)) return 0;
   if (mt128 * (npad / 64) >= 512) return 1;
