@@ -245,8 +245,11 @@ def test_planes_gemm_chain(lib, B, L, k, n):
         assert (out2.cpu() - F.linear(gref, w2)).abs().max().item() < TOL_OP
 
 
-def test_attention_planes_output(lib):
-    B, L, H = 2, 256, 4
+@pytest.mark.parametrize("L,wide", [(256, "0"), (256, "1"), (512, "1")])
+def test_attention_planes_output(lib, L, wide, monkeypatch):
+    """hi/lo plane output (the operand of the to_out planes GEMM) from both forms of the kernel."""
+    monkeypatch.setenv("PF_ATTN_WIDE", wide)
+    B, H = 2, 4
     c = H * 64
     qkv = rnd((B, L, 3 * c), 101)
     q, k, v = (t.reshape(B, L, H, 64) for t in qkv.chunk(3, dim=-1))
@@ -262,6 +265,35 @@ def test_attention_planes_output(lib):
     torch.cuda.synchronize()
     pl = op.view(torch.bfloat16).float().cpu().view(2, B, L, c)
     assert (pl[0] + pl[1] - ref).abs().max().item() < 3e-4
+
+
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_attention_running_maximum_extremes(lib, wide, monkeypatch):
+    """Scores whose row maxima keep growing from tile to tile (key norms ramp up along the sequence: the reference exponent of the
+    256-query form moves several times per row, the 128-query form rescales on every tile), rows dominated by one late key, and rows
+    whose scores are all far below the first tile's - against the fp32 softmax."""
+    monkeypatch.setenv("PF_ATTN_WIDE", wide)
+    B, L, H = 1, 1024, 4
+    c = H * 64
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, L, H, 64, generator=g) * 2.0
+    k = torch.randn(B, L, H, 64, generator=g) * torch.linspace(0.05, 3.0, L).view(1, L, 1, 1)
+    v = torch.randn(B, L, H, 64, generator=g)
+    k[:, 900, 1] = q[:, 17, 1] * 1.5            # query 17 of head 1 is dominated by key 900
+    k[:, :64, 2] *= 40.0                         # head 2: the first tile holds the extremes of both signs
+    qkv = torch.cat([q.reshape(B, L, c), k.reshape(B, L, c), v.reshape(B, L, c)], dim=-1).contiguous()
+    att = (torch.einsum("bihd,bjhd->bhij", q.double(), k.double()) * 0.125).softmax(-1)
+    ref = torch.einsum("bhij,bjhd->bihd", att, v.double()).reshape(B, L, c).float()
+    planes = torch.zeros(B * L * 3 * c, dtype=torch.float32, device="cuda")
+    dummy = torch.empty(1, device="cuda")
+    run_conv(lib, x0=dev(qkv), c0=3 * c, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, torch.eye(3 * c)), n=3 * c,
+             out=dummy, ld_out=3 * c, precision=1, qkv_planes=planes)
+    out = torch.empty(B, L, c, device="cuda")
+    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, None, B, H, L, _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < 1e-3, err                       # operands are bf16 hi+lo (2^-17 relative) and the scores reach +-400 here
 
 
 @pytest.mark.parametrize("B,L,H", [(2, 1024, 4), (3, 256, 4)])
