@@ -100,3 +100,27 @@ def test_full_unet_stress_bf16x3(batch, reps):
     ref = m(x, t, c).clone()
     bad = sum(int(not torch.equal(m(x, t, c), ref)) for _ in range(reps))
     assert bad == 0, f"{bad}/{reps} evaluations differ"
+
+
+@pytest.mark.parametrize("L,B,wide", [(1024, 16, "1"), (1024, 16, "0"), (256, 16, "0"), (512, 5, "1")])
+def test_attention_is_bit_reproducible(L, B, wide, monkeypatch):
+    """Both forms of the bf16x3 self-attention (hand-counted LDS / direct-to-LDS waits, hidden fragment loads, a static filler
+    schedule) repeated on one input: every repeat must give the same bits, in both output formats."""
+    from polyffusion_amd import _lib
+    monkeypatch.setenv("PF_ATTN_WIDE", wide)
+    lib = _lib.load()
+    H, c = 4, 256
+    g = torch.Generator().manual_seed(L + B)
+    planes = (torch.randn(B * L * 3 * c * 2, generator=g) * 0.7).to(torch.bfloat16).cuda()
+    st = _lib.current_stream()
+    for as_planes in (False, True):
+        outs = []
+        for _ in range(24):
+            out = torch.zeros(B, L, c, device="cuda")
+            args = (None, c, out.data_ptr()) if as_planes else (out.data_ptr(), c, None)
+            _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), args[0], args[1], args[2], B, H, L, st))
+            outs.append(out)
+        torch.cuda.synchronize()
+        bad = sum(not torch.equal(outs[0], o) for o in outs[1:])
+        assert bad == 0, f"{bad}/23 repeats differ (planes output: {as_planes})"
+        assert torch.isfinite(outs[0]).all() if not as_planes else True
