@@ -2,15 +2,21 @@
 """bench.py - denoising steps/sec on MI355X for BASELINE.json config 2
 (sdf_chd8bar conditional generation, batch 16 per GPU, DDPM sampler).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: re-executes itself under torch.distributed.run, one rank per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one iteration of SDFSampler.paint's loop on a batch of 16 piano rolls: the
-conditional UNet evaluation (uncond_scale = 1 -> one eval per sample), two on-device noise draws
-and the fused DDPM/RePaint update - exactly what `inference_sdf` executes per reverse step.
-Inputs (x_T, chord condition from the HIP chord encoder, weights) are resident in HBM before
-the timed region.  Rank 0 prints ONE JSON line; `value` is the whole-job aggregate (sum over GPUs,
-weak scaling: every GPU denoises its own batch of 16).
+One "step" = one iteration of SDFSampler.paint's loop on a batch of 16 piano rolls (`SDFSampler.repaint_step`, the method paint()
+itself runs): the conditional UNet evaluation (uncond_scale = 1 -> one eval per sample) and the fused DDPM/RePaint update with its two
+noise draws - exactly what `inference_sdf` executes per reverse step.  As in paint(), what the denoiser derives from (t, cond) alone is
+prepared once before the loop (`sampler.prepare`).  Inputs (x_T, chord condition from the HIP chord encoder, weights) are resident in
+HBM before the timed region.  Rank 0 prints ONE JSON line; `value` is the whole-job aggregate (sum over GPUs, weak scaling: every GPU
+denoises its own batch of 16).
+
+Timing protocol: W warm-up steps, then `--windows` (default 5) back-to-back windows of EXACTLY K steps, each between barrier +
+synchronize pairs (host clock, max over ranks).  `value` / `ms_per_step` are the MEDIAN window; every window and the spread are in
+the line (`windows_ms_per_step`), next to the average shader clock the GPU sustained over each window (`sclk_mhz`, from two probe
+kernels that read the shader-cycle and the constant-rate counters) - the part is power-managed, and box-to-box differences of the same
+binary show up there.
 
 Extra objects (see DESIGN.md "Measurement"):
   roofline     - the dominant kernel family (the 3x3 convolutions, conv_bf16x3.hip: error-compensated bf16 split on the
@@ -121,19 +127,76 @@ def cpu_baseline(params, reps=3):
             "thread_sweep_steps_per_s": {str(n): round(1.0 / t, 4) for n, t in probes.items()}}
 
 
-def timed_loop(step_fn, x, t_step, steps):
+class ClockProbe:
+    """Average shader clock over a stretch of stream work: pf_clock_probe before and after it.  The reference counter's rate is
+    calibrated once against the host clock (two probes 50 ms apart) instead of being assumed."""
+
+    def __init__(self, dev):
+        self.lib = _lib.load()
+        self.buf = torch.zeros(2, 8, 2, dtype=torch.int64, device=dev)   # [begin | end][XCD][shader cycles, reference ticks]
+        self.ref_hz = None
+        try:
+            self._probe(0); torch.cuda.synchronize(); t0 = time.perf_counter()
+            time.sleep(0.05)
+            self._probe(1); torch.cuda.synchronize(); t1 = time.perf_counter()
+            b = self.buf.tolist()
+            rates = sorted((b[1][x][1] - b[0][x][1]) / (t1 - t0) for x in range(8) if b[0][x][1] and b[1][x][1])
+            hz = rates[len(rates) // 2] if rates else 0.0
+            self.ref_hz = hz if 1e6 < hz < 1e10 else None
+        except Exception:
+            self.ref_hz = None
+
+    def _probe(self, slot):
+        _lib.check(self.lib.pf_clock_probe(self.buf[slot].data_ptr(), _lib.current_stream()), "pf_clock_probe")
+
+    def begin(self):
+        self.buf.zero_()
+        self._probe(0)
+
+    def end_mhz(self):
+        """call after the stream has been synchronised; per-XCD average MHz {"median", "min", "max"} or None when the counters are unusable"""
+        self._probe(1); torch.cuda.synchronize()
+        b = self.buf.tolist()
+        if not self.ref_hz:
+            return None
+        mhz = sorted((b[1][x][0] - b[0][x][0]) / (b[1][x][1] - b[0][x][1]) * self.ref_hz / 1e6
+                     for x in range(8) if b[0][x][1] and b[1][x][1] > b[0][x][1])
+        if not mhz:
+            return None
+        return {"median": round(mhz[len(mhz) // 2], 1), "min": round(mhz[0], 1), "max": round(mhz[-1], 1), "xcds": len(mhz)}
+
+
+def smi_snapshot():
+    """sclk / power as rocm-smi reports them (outside the timed region); {} when the tool is absent or prints nothing usable"""
+    import shutil, subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        out = subprocess.run([exe, "-d", str(torch.cuda.current_device()), "--showclocks", "--showpower", "--json"], capture_output=True,
+                             text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        keep = {k: v for k, v in card.items() if any(s in k.lower() for s in ("sclk", "power", "mclk"))}
+        return dict(list(keep.items())[:6])
+    except Exception:
+        return {}
+
+
+def timed_loop(step_fn, x, t_step, steps, probe=None):
     """K steps between barrier + synchronize pairs (the driver contract: host clock, max over ranks) with a HIP-event pair on the
-    launch stream around the same K steps.  Returns (x, t_step, host seconds (max over ranks), event seconds)."""
+    launch stream around the same K steps.  Returns (x, t_step, host seconds (max over ranks), event seconds,
+    average shader clock in MHz or None)."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); pfdist.barrier()
     t0 = time.perf_counter()
     e0.record()
+    if probe:
+        probe.begin()
     for _ in range(steps):
         x = step_fn(x, t_step); t_step = max(t_step - 1, 1)
     e1.record()
     torch.cuda.synchronize(); pfdist.barrier()
     host = pfdist.max_over_ranks(time.perf_counter() - t0)
-    return x, t_step, host, e0.elapsed_time(e1) * 1e-3
+    mhz = probe.end_mhz() if probe else None
+    return x, t_step, host, e0.elapsed_time(e1) * 1e-3, mhz
 
 
 def profiled_pass(unet, step_fn, x, t_step, n_steps, precision, dump=False):
@@ -200,11 +263,12 @@ def config3_line(model, params, steps=10):
     d = DDIMSampler(model.ldm, 50, "uniform", 0.0, seed=4)
     shape = (B, params.out_channels, params.img_h, params.img_w)
     x = d.randn(shape, dev)
+    prep = d.prepare(cond, uncond_scale=5.0, uncond_cond=uc)   # what DDIMSampler.paint hoists out of its loop
 
     def run(n):
         xx = x
         for i, step in enumerate(np.flip(d.time_steps)[:n]):
-            xx, _, _ = d.p_sample(xx, cond, None, int(step), 49 - i, uncond_scale=5.0, uncond_cond=uc)
+            xx, _, _ = d.p_sample(xx, cond, None, int(step), 49 - i, uncond_scale=5.0, uncond_cond=uc, prep=prep)
         return xx
 
     run(2)
@@ -223,6 +287,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=5, help="back-to-back timed windows of --steps steps each; the median window is reported")
     ap.add_argument("--profile-steps", type=int, default=2, help="profiled steps for the roofline object (0 disables)")
     ap.add_argument("--fp32-steps", type=int, default=10, help="steps of the exact-fp32-MFMA mode measured in the same run (0 disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -232,12 +297,21 @@ def main():
     ap.add_argument("--dump-launches", action="store_true", help="print one line per kernel launch of a profiled step (stderr)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher - one rank per GPU under torch.distributed.run (rendezvous on
+        # 127.0.0.1, a free port), same arguments; rank 0 of that job prints the ONE JSON line
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        sys.stdout.flush()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank, world, local = pfdist.init_from_env()
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if args.gpus != 1 or world != 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     _lib.require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
     params = preset("sdf_chd8bar")
@@ -254,25 +328,24 @@ def main():
     shape = (BATCH, params.out_channels, params.img_h, params.img_w)
     zeros = torch.zeros(shape, device=dev)
     x = sampler.q_sample(zeros, params.n_steps - 1, sampler.randn(shape, dev))  # what Experiments.predict feeds paint()
-    n = x.numel()
-    lib = _lib.load()
-    import ctypes as C
+    prep = sampler.prepare(cond)     # once per paint(): time-bias table + collapsed cross-attention biases (not part of a step)
 
-    def step_fn(x_t, step):
-        coef = sampler._coef(step)
-        noise_q = sampler.randn(shape, dev) if step > 0 else None
-        e_t = sampler._eps(x_t, cond, step, 1.0, None, None)
-        noise_p = sampler.randn(shape, dev) if step > 0 else None
-        out = torch.empty_like(x_t)
-        _lib.check(lib.pf_ddpm_step(x_t.data_ptr(), e_t.data_ptr(), _lib.ptr(noise_p), _lib.ptr(noise_q), zeros.data_ptr(),
-                                    zeros.data_ptr(), C.byref(coef), out.data_ptr(), n, _lib.current_stream()))
-        return out
+    def step_fn(x_t, step):          # the loop body of SDFSampler.paint with a known region (orig = mask = 0, as Experiments.predict passes)
+        return sampler.repaint_step(x_t, cond, step, zeros, zeros, prep=prep)
 
+    probe = ClockProbe(dev)
+    smi_before = smi_snapshot() if rank == 0 else {}
     t_step = params.n_steps - 1
     for _ in range(args.warmup):
         x = step_fn(x, t_step); t_step = max(t_step - 1, 1)
-    x, t_step, elapsed, ev_elapsed = timed_loop(step_fn, x, t_step, args.steps)
+    wins = []
+    for _ in range(max(1, args.windows)):
+        x, t_step, el, ev, mhz = timed_loop(step_fn, x, t_step, args.steps, probe)
+        wins.append((el, ev, mhz))
     assert torch.isfinite(x).all(), "non-finite sample"
+    smi_after = smi_snapshot() if rank == 0 else {}
+    order = sorted(range(len(wins)), key=lambda i: wins[i][0])
+    elapsed, ev_elapsed, med_mhz = wins[order[len(order) // 2]]
 
     ms_per_step = elapsed / args.steps * 1e3
     # work actually executed (never count skipped work): the bf16x3 plan folds nearest-x2 + conv3x3 into four 2x2 convs
@@ -285,8 +358,16 @@ def main():
         "config": {"workload": "sdf_chd8bar cond generation, batch 16 per GPU, 1000-step DDPM sampler loop body "
                                "(BASELINE.json configs[1]); weights: deterministic synthetic, 41.08M params",
                    "global_batch": BATCH * world, "unet_evals_per_step": BATCH * world, "parallelism": f"batch-shard x{world}",
-                   "weight_broadcast_s": round(bcast_s, 4), "launches_per_step": unet.n_launches(BATCH) + 3},
+                   "weight_broadcast_s": round(bcast_s, 4), "launches_per_step": unet.n_launches(BATCH, prepared=True) + 1},
         "ms_per_step_hip_events": round(ev_elapsed / args.steps * 1e3, 4),
+        "windows": len(wins), "windows_ms_per_step": [round(w[0] / args.steps * 1e3, 4) for w in wins],
+        "windows_spread_pct": round((max(w[0] for w in wins) - min(w[0] for w in wins)) / elapsed * 100, 2),
+        "window_rule": "value / ms_per_step = the MEDIAN of the windows (each exactly --steps steps between barrier + synchronize pairs)",
+        "sclk_mhz": {"median_window": med_mhz, "per_window": [w[2] for w in wins],
+                     "how": "average shader clock of the XCDs over each timed window = d(s_memtime) / d(s_memrealtime) per XCD between two probe "
+                            "kernels on the launch stream (median / min / max over the XCDs), reference counter calibrated against the host clock "
+                            "(%s Hz)" % (None if probe.ref_hz is None else round(probe.ref_hz)),
+                     "rocm_smi_before": smi_before, "rocm_smi_after": smi_after},
         "ranks_seen": ranks_seen, "devices_seen": devices_seen,
         "path_tflops": round(f_eval * BATCH * world * args.steps / elapsed / 1e12, 3),
         "path_frac_of_f32_mfma_peak": round(f_eval * BATCH * args.steps / elapsed / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
@@ -337,15 +418,19 @@ def main():
                                               "therefore a lower bound, *_event_corrected subtract one pair per launch and are an upper bound - "
                                               "rocprofv3's per-kernel averages (profiles/) lie between the two"}
         out["kernel_ms_per_step"] = {KIND_NAMES[kind]: round(v[1] / args.profile_steps, 4) for kind, v in sorted(agg.items())}
+        # the same with one empty event pair taken off every launch: what rocprofv3's per-kernel durations add up to (profiles/)
+        out["kernel_ms_per_step_corrected"] = {KIND_NAMES[kind]: round(max(v[1] - v[0] * ev_pair_ms, 0.0) / args.profile_steps, 4)
+                                               for kind, v in sorted(agg.items())}
+        out["kernel_ms_per_step_corrected"]["sum"] = round(sum(out["kernel_ms_per_step_corrected"].values()), 4)
 
     if args.fp32_steps > 0 and args.precision == "bf16x3":
         # the exact-fp32-MFMA mode in the same run, same workload (every rank runs it so the barriers line up)
         unet.set_precision("f32")
         for _ in range(2):
             x = step_fn(x, t_step)
-        x, t_step, el32, _ = timed_loop(step_fn, x, t_step, args.fp32_steps)
+        x, t_step, el32, _, mhz32 = timed_loop(step_fn, x, t_step, args.fp32_steps, probe)
         fp32 = {"steps_per_s": round(world * args.fp32_steps / el32, 4), "ms_per_step": round(el32 / args.fp32_steps * 1e3, 4),
-                "steps": args.fp32_steps,
+                "steps": args.fp32_steps, "sclk_mhz": mhz32,
                 "path_frac_of_157": round(F_MIN_PER_SAMPLE_EVAL * BATCH * args.fp32_steps / el32 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)}
         if rank == 0 and args.profile_steps > 0:
             x, agg32 = profiled_pass(unet, step_fn, x, t_step, 1, "f32")

@@ -74,6 +74,42 @@ size_t pf_unet_workspace_bytes(const pf_unet* u, int batch, int n_cond);
 int pf_unet_forward(pf_unet* u, const float* x, const int64_t* t, const float* cond, int batch, int n_cond,
                     float* eps, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- step-invariant prefix, hoisted out of the reverse loop -----------------------------------------------------------
+ * Two parts of UNetModel.forward do not depend on x: the time MLP + every ResBlock's emb_layers (unet.py:181-182, 286-289:
+ * a function of t only) and, with ONE context token, the whole cross-attention (unet_attention.py:186-212, 261-293: softmax over
+ * one key is 1, so attn2(x, c) = to_out(to_v(c)) for every position: a function of cond only).  A sampler knows every t of its
+ * loop in advance and holds cond fixed, so it computes both ONCE and hands them to every forward of the loop:
+ *   pf_unet_prepare_time - rows r = 0 .. n_rows-1 of `table` [n_rows][pf_unet_time_bias_width] = the additive time biases of all
+ *                          ResBlocks for time-step VALUE r (what forward computes from t == r); scratch: n_rows * 4 * channels floats
+ *   pf_unet_prepare_cond - `cross` [batch][pf_unet_cross_bias_width] = to_out(to_v(cond[b])) + bias of every transformer block
+ *                          (n_cond == 1 only); scratch: batch * width floats
+ * Both buffers are caller-owned device memory; nothing is cached inside the library.  pf_unet_forward_prepared with prep == NULL
+ * (or with NULL members) computes the missing part itself, exactly like pf_unet_forward; results are bit-identical either way.
+ * With a time table every t[b] must lie in [0, n_time_rows) (values outside are clamped for memory safety). */
+typedef struct pf_unet_prepared {
+  const float* time_table; int32_t n_time_rows;   /* from pf_unet_prepare_time, or NULL */
+  const float* cross_bias;                         /* from pf_unet_prepare_cond for THIS cond / batch, or NULL */
+} pf_unet_prepared;
+int pf_unet_time_bias_width(const pf_unet* u);
+int pf_unet_cross_bias_width(const pf_unet* u);
+int pf_unet_prepare_time(pf_unet* u, int n_rows, float* table, void* scratch, size_t scratch_bytes, void* stream);
+int pf_unet_prepare_cond(pf_unet* u, const float* cond, int batch, float* cross, void* scratch, size_t scratch_bytes, void* stream);
+int pf_unet_forward_prepared(pf_unet* u, const float* x, const int64_t* t, const float* cond, int batch, int n_cond,
+                             const pf_unet_prepared* prep, float* eps, void* workspace, size_t workspace_bytes, void* stream);
+/* kernel launches of one forward; has_time / has_cross: with that member of pf_unet_prepared supplied */
+int pf_unet_n_launches_prepared(const pf_unet* u, int batch, int n_cond, int has_time, int has_cross);
+
+/* Plan options, per handle (default PF_OPT_AUTO for all): which of two equivalent kernel forms the plan launches.
+ *   PF_OPT_MLP_FUSED  - transformer feed-forward (+ proj_out) as ONE launch per 64-token tile vs LayerNorm planes + GeGLU GEMM + FF-out
+ *                       GEMM + proj_out (bit-identical results); auto: fused when its last round of workgroups is >= 85 % full
+ *   PF_OPT_ATTN_WIDE  - self-attention with 256-query vs 128-query workgroups (equal up to summation order); auto: 256 when L % 256 == 0
+ *                       and that still gives 3/4 of the CUs a workgroup
+ *   PF_OPT_CONV_T16   - 16x16-pixel tile for the 64-output-channel 3x3 convs with >= 128 input channels vs the 8x16 tile */
+enum { PF_OPT_MLP_FUSED = 0, PF_OPT_ATTN_WIDE = 1, PF_OPT_CONV_T16 = 2, PF_OPT_COUNT = 3 };
+enum { PF_OPT_AUTO = -1, PF_OPT_OFF = 0, PF_OPT_ON = 1 };
+int pf_unet_set_option(pf_unet* u, int option, int value);
+int pf_unet_get_option(const pf_unet* u, int option);
+
 /* Per-launch profiling: when enabled, forward brackets every kernel launch with hipEvents
  * on the launch stream.  pf_unet_profile_read synchronises those events and returns, per
  * launch: a kernel-family id (PF_K_*), elapsed ms and the algorithmic FLOPs of the launch. */
@@ -112,6 +148,21 @@ int pf_ddim_step(const float* x, const float* eps, const float* noise, const flo
  * elem_offset = index of out[0] in the global (unsharded) tensor. */
 int pf_randn(float* out, size_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, void* stream);
 
+/* The same updates with the noise drawn INSIDE the kernel (no noise tensor in HBM, two launches per step less): element i of draw d is
+ * exactly what pf_randn(seed, d, elem_offset) writes at i, so results are bit-identical to pf_randn + pf_ddpm_step / pf_ddim_step.
+ * DDPM: noise_q = draw `draw_q` (only when orig != NULL), noise_p = draw `draw_p` - the reference's order is q then p
+ * (sampler_sdf.py:317-321, 153-160).  DDIM: noise = draw `draw` (sigma != 0 steps only; orig_noise stays a tensor: the reference's DDIM
+ * paint re-uses one fixed tensor, sampler_ddim.py:355-359).  n and elem_offset must be multiples of 4 (one Philox call = 4 normals). */
+int pf_ddpm_step_rng(const float* x, const float* eps, const float* orig, const float* mask, const pf_ddpm_coef* c,
+                     uint64_t seed, uint64_t draw_q, uint64_t draw_p, uint64_t elem_offset, float* x_out, size_t n, void* stream);
+int pf_ddim_step_rng(const float* x, const float* eps, const float* orig, const float* orig_noise, const float* mask, const pf_ddim_coef* c,
+                     uint64_t seed, uint64_t draw, uint64_t elem_offset, float* x_out, size_t n, void* stream);
+
+/* Measurement aid (bench.py): writes {shader-cycle counter, constant-rate reference counter} of the moment the probe kernel runs into
+ * row x of out[8][2] for every XCD x (XCDs have counters and clocks of their own; rows of XCDs the part does not have stay
+ * untouched); two probes around a stretch of stream work give the average shader clock each XCD sustained over it. */
+int pf_clock_probe(uint64_t* out8x2, void* stream);
+
 /* ---- replayable reverse step: everything that changes from one step to the next - the table row, the
  * time-step value fed to the denoiser, the noise draw counter - lives in a small device-resident state, so ONE captured
  * hipGraph of {begin, randn, pf_unet_forward, randn, step, end} is replayed for every step of the loop.  `table` is the
@@ -126,6 +177,12 @@ int pf_ddpm_step_dev(const float* x, const float* eps, const float* noise_p, con
                      const float* mask, const pf_ddpm_coef* table, const pf_step_state* dev_state, float* x_out, size_t n, void* stream);
 int pf_ddim_step_dev(const float* x, const float* eps, const float* noise, const float* orig, const float* orig_noise,
                      const float* mask, const pf_ddim_coef* table, const pf_step_state* dev_state, float* x_out, size_t n, void* stream);
+/* in-kernel noise, draw indices from the device state: DDPM q = state.draws (orig != NULL only), p = the next one; DDIM = state.draws */
+int pf_ddpm_step_rng_dev(const float* x, const float* eps, const float* orig, const float* mask, const pf_ddpm_coef* table,
+                         const pf_step_state* dev_state, uint64_t seed, uint64_t elem_offset, float* x_out, size_t n, void* stream);
+int pf_ddim_step_rng_dev(const float* x, const float* eps, const float* orig, const float* orig_noise, const float* mask,
+                         const pf_ddim_coef* table, const pf_step_state* dev_state, uint64_t seed, uint64_t elem_offset, float* x_out,
+                         size_t n, void* stream);
 
 /* ---- weight broadcast over RCCL / xGMI.  The path has ONE exchange: rank 0 ships the packed weight
  * blob at start-up; the step loop has no collective.  librccl.so is opened on first use (dlopen), so a single-GPU process
@@ -207,24 +264,6 @@ int pf_mlp_geglu_fused(const float* x, int batch, int l, const float* ln_gamma, 
 int pf_mlp_geglu_proj_fused(const float* x, int batch, int l, const float* ln_gamma, const float* ln_beta, float ln_eps,
                             const void* w1_bf16x3, const float* b1, const void* w2_bf16x3, const float* b2,
                             const void* w3_bf16x3, const float* b3, const float* res3, float* out, float* stats3, void* stream);
-/* Everything of a BasicTransformerBlock that follows self-attention, per 64-token tile in ONE launch (unet_attention.py:115-124 with the
- * n_cond == 1 cross-attention collapsed to a per-sample bias, optionally + SpatialTransformer.proj_out :77-79):
- *     x1  = attn_planes . Wo + bo + cross_bias[sample] + x0          (attn1.to_out + residual; x1 is also written to `x1`)
- *     x2  = x1 + ff(norm3(x1))
- *     out = x2                          (w3 == NULL; fp32 `out` or plane pair `out_planes`)
- *         = res3 + b3 + W3 . x2         (proj_out chained; `stats3` as in pf_mlp_geglu_proj_fused)
- * attn_planes: pf_attention_bf16x3's o_planes; every weight is the bf16x3 packing of its [256][K] matrix (w1 GeGLU-interleaved).
- * Bit-identical to pf_conv2d(a_planes, res) + pf_mlp_geglu(_proj)_fused. */
-typedef struct pf_tblock_tail_args {
-  const void* attn_planes; const void* wo; const float* bo; const float* cross_bias; int32_t ld_cross_bias; const float* x0;
-  float* x1;
-  int32_t batch, l;
-  const float* ln_gamma; const float* ln_beta; float ln_eps;
-  const void* w1; const float* b1; const void* w2; const float* b2;
-  const void* w3; const float* b3; const float* res3; float* stats3;
-  float* out; void* out_planes;
-} pf_tblock_tail_args;
-int pf_transformer_tail_fused(const pf_tblock_tail_args* a, void* stream);
 
 /* Implicit-GEMM convolution / linear on NHWC with fused prologue and epilogue (fp32 MFMA).
  *   ks 1|3, stride 1|2, ups 0|1 (nearest x2 folded into the input read, unet.py:236-238)
@@ -265,6 +304,10 @@ typedef struct pf_conv_args {
   const float* gn_stats1; int32_t gn_tiles1;
   const float* gn_gamma; const float* gn_beta;
   float gn_eps; int32_t gn_groups;
+  /* optional: row of `sbias` per sample - sbias[sbias_rows[b]] instead of sbias[b] (the hoisted time-bias table indexed by the
+   * device-resident t[b]); rows outside [0, sbias_nrows) are clamped */
+  const int64_t* sbias_rows; int32_t sbias_nrows;
+  int32_t no_t16;          /* != 0: never pick the 16x16-pixel tile (PF_OPT_CONV_T16 = off) */
 } pf_conv_args;
 /* scratch bytes a launch with these arguments would like for split-K (0 = the launch does not split) */
 size_t pf_conv_splitk_ws_bytes(const pf_conv_args* a);
@@ -279,7 +322,8 @@ int pf_conv2d(const pf_conv_args* a, void* stream);
  * along the last dim (unet_attention.py:261-293). d_head in {32,64}. */
 /* self-attention on the pre-split planes written by pf_conv2d(qkv_planes=...): d_head 64, L %% 128 == 0 (bf16x3 split MFMA);
  * the result goes to fp32 `o` or, when o_planes != NULL, to bf16 hi/lo planes [M][C] | [M][C] for a following planes GEMM */
-int pf_attention_bf16x3(const void* qkv_planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, void* stream);
+int pf_attention_bf16x3(const void* qkv_planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, int form /* PF_OPT_AUTO | 0: 128-query | 1: 256-query workgroups */,
+                        void* stream);
 int pf_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                  int batch, int n_heads, int d_head, int lq, int lk, void* stream);
 

@@ -35,12 +35,13 @@ class DdimCoef(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("s1m", "sqrt_a", "sqrt_aprev", "dir_coef", "sigma", "q_sqrt_a", "q_s1m")]
 
 
-class TBlockTailArgs(C.Structure):
-    """pf_tblock_tail_args (include/pfhip.h)."""
-    _fields_ = [("attn_planes", C.c_void_p), ("wo", C.c_void_p), ("bo", C.c_void_p), ("cross_bias", C.c_void_p), ("ld_cross_bias", C.c_int32),
-                ("x0", C.c_void_p), ("x1", C.c_void_p), ("batch", C.c_int32), ("l", C.c_int32), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
-                ("ln_eps", C.c_float), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("w3", C.c_void_p),
-                ("b3", C.c_void_p), ("res3", C.c_void_p), ("stats3", C.c_void_p), ("out", C.c_void_p), ("out_planes", C.c_void_p)]
+class UNetPrepared(C.Structure):
+    """pf_unet_prepared (include/pfhip.h): the step-invariant prefix a sampler computes once per loop."""
+    _fields_ = [("time_table", C.c_void_p), ("n_time_rows", C.c_int32), ("cross_bias", C.c_void_p)]
+
+
+OPT_MLP_FUSED, OPT_ATTN_WIDE, OPT_CONV_T16 = 0, 1, 2
+OPT_AUTO, OPT_OFF, OPT_ON = -1, 0, 1
 
 
 class ConvArgs(C.Structure):
@@ -63,6 +64,7 @@ class ConvArgs(C.Structure):
         ("skip_w", C.c_void_p), ("skip_bias", C.c_void_p),
         ("gn_stats0", C.c_void_p), ("gn_tiles0", C.c_int32), ("gn_stats1", C.c_void_p), ("gn_tiles1", C.c_int32),
         ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float), ("gn_groups", C.c_int32),
+        ("sbias_rows", C.c_void_p), ("sbias_nrows", C.c_int32), ("no_t16", C.c_int32),
     ]
 
 
@@ -81,6 +83,15 @@ SIGNATURES = {
     "pf_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "pf_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_unet_forward_prepared": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(UNetPrepared),
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_unet_time_bias_width": (C.c_int, [C.c_void_p]),
+    "pf_unet_cross_bias_width": (C.c_int, [C.c_void_p]),
+    "pf_unet_prepare_time": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_unet_prepare_cond": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_unet_n_launches_prepared": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pf_unet_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "pf_unet_get_option": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_unet_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_unet_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), c_float_p, C.POINTER(C.c_double), C.c_int]),
     "pf_unet_n_launches": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
@@ -89,6 +100,11 @@ SIGNATURES = {
     "pf_axpby": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_ddim_step": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(DdimCoef), C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_randn": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "pf_ddpm_step_rng": (C.c_int, [C.c_void_p] * 4 + [C.POINTER(DdpmCoef), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_ddim_step_rng": (C.c_int, [C.c_void_p] * 5 + [C.POINTER(DdimCoef), C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_ddpm_step_rng_dev": (C.c_int, [C.c_void_p] * 6 + [C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_ddim_step_rng_dev": (C.c_int, [C.c_void_p] * 7 + [C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_clock_probe": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pf_step_state_set": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
     "pf_step_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pf_step_end": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
@@ -121,13 +137,12 @@ SIGNATURES = {
     "pf_mlp_geglu_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_mlp_geglu_proj_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 10),
-    "pf_transformer_tail_fused": (C.c_int, [C.POINTER(TBlockTailArgs), C.c_void_p]),
     "pf_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "pf_conv_stats_tiles": (C.c_int, [C.POINTER(ConvArgs)]),
     "pf_conv_splitk_ws_bytes": (C.c_size_t, [C.POINTER(ConvArgs)]),
     "pf_gn_finalize_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "pf_attention_bf16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pf_attention_bf16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pf_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }

@@ -184,8 +184,8 @@ int launch_attention(const float* q, int ldq, const float* k, int ldk, const flo
   dim3 grid((lq + 127) / 128, n_heads, batch);
   if (d_head == 64) {
     constexpr size_t lds = (size_t)(2 * 64 * 68 + 2 * 64 * 64) * sizeof(float);
-    static bool done = false;
-    if (!done) { PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    static std::atomic<uint64_t> attr_done{0};
+    if (int rc = set_max_lds_once(reinterpret_cast<const void*>(attn_kernel<64>), (int)lds, attr_done)) return rc;
     hipLaunchKernelGGL(attn_kernel<64>, grid, dim3(256), lds, stream, p);
   } else {
     constexpr size_t lds = (size_t)(2 * 64 * 36 + 2 * 64 * 32) * sizeof(float);

@@ -586,22 +586,19 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
   }
 }
 
-int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, hipStream_t stream) {
+int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, int form, hipStream_t stream) {
   PF_REQUIRE(planes && (o || o_planes) && batch > 0 && n_heads > 0 && l > 0 && l % 128 == 0, "attention_bf3: L must be a positive multiple of 128");
-  // the 256-query form where it still gives most CUs a workgroup (PF_ATTN_WIDE = 0 / 1 pins the form: tests, A/B runs)
-  const char* force = getenv("PF_ATTN_WIDE");
-  const bool wide = l % 256 == 0 && (force ? force[0] == '1' : (l / 256) * n_heads * batch >= 192);
+  PF_REQUIRE(form == PF_OPT_AUTO || form == 0 || (form == 1 && l % 256 == 0), "attention_bf3: form must be auto, 0 (128-query) or 1 (256-query, L %% 256 == 0)");
+  // auto: the 256-query form where it still gives three quarters of the CUs a workgroup
+  const bool wide = l % 256 == 0 && (form == PF_OPT_AUTO ? (l / 256) * n_heads * batch >= num_cus() * 3 / 4 : form == 1);
   AttnP3 p{static_cast<const __bf16*>(planes), o, ldo, static_cast<__bf16*>(o_planes), batch, n_heads, l, 0.125f,
            make_fastdiv(wide ? l / 256 : l / 128), make_fastdiv(n_heads)};
   // (an 8-wave / 256-query form - half the K/V^T tile traffic per query - was measured and lost: its waves run S / softmax / PV in
   // lockstep behind one barrier, so the matrix pipe idles during every softmax, while two independent 4-wave workgroups per CU drift
   // apart and fill each other's gaps)
-  static bool done = false;
-  if (!done) {
-    PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf3_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768));
-    PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf3_wide_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
-    done = true;
-  }
+  static std::atomic<uint64_t> done_n{0}, done_w{0};
+  if (int rc = set_max_lds_once(reinterpret_cast<const void*>(attn_bf3_kernel<4, 2>), 2 * 32768, done_n)) return rc;
+  if (int rc = set_max_lds_once(reinterpret_cast<const void*>(attn_bf3_wide_kernel<4>), 4 * 32768, done_w)) return rc;
   if (wide) hipLaunchKernelGGL((attn_bf3_wide_kernel<4>), dim3((l / 256) * n_heads * batch), dim3(256), 4 * 32768, stream, p);
   else hipLaunchKernelGGL((attn_bf3_kernel<4, 2>), dim3((l / 128) * n_heads * batch), dim3(256), 2 * 32768, stream, p);
   PF_CHECK_HIP(hipGetLastError());

@@ -50,11 +50,22 @@ constexpr int conv_bf3_row_pitch() {
   return (KS != 1 && STRIDE == 1 && BN >= 128) ? (TWIN * 40 + 127) / 128 * 128 : TWIN * 40;
 }
 
+// Weight-ring depth.  3x3: three slots, two tiles in flight across every barrier - enough where a tap carries 12-24 MFMAs per wave
+// (1.4-2.3 k cycles per tap against ~1 us from issue to landing of a direct-to-LDS load).  The K-split tile of the 16x16 level (KG == 2:
+// 6 MFMAs per wave and tap) runs its taps in ~0.6 k cycles when nothing waits, so two tiles of lead are ~1.2 k cycles and every tap
+// waited ~0.4 k for its weights: it gets a deeper ring (its single workgroup per CU has the LDS for it).  A ring that does not divide
+// the taps addresses its slots through a register instead of instruction immediates (see DYN in the kernel).
+#ifndef PF_KG2_RING
+#define PF_KG2_RING 5
+#endif
+template <int KS, int KG>
+constexpr int conv_bf3_wring() { return KS == 3 ? (KG == 2 ? PF_KG2_RING : 3) : 2; }
+
 // LDS bytes of one wave group: the main loop's halo image + weight ring, or the fused 1x1 phase's double buffers
-template <int KS, int STRIDE, int TH, int TW, int BN, bool SKIP>
+template <int KS, int STRIDE, int TH, int TW, int BN, bool SKIP, int KG = 1>
 constexpr size_t conv_bf3_group_lds() {
   constexpr int THIN = (TH - 1) * STRIDE + KS, TWIN = (TW - 1) * STRIDE + KS;
-  constexpr int NABUF = (KS == 1) ? 2 : 1, WRING = (KS == 3) ? 3 : 2;
+  constexpr int NABUF = (KS == 1) ? 2 : 1, WRING = conv_bf3_wring<KS, KG>();
   constexpr size_t main_b = (size_t)(2 * NABUF * THIN * conv_bf3_row_pitch<KS, STRIDE, TWIN, BN>() + WRING * 8 * BN * 8) * 2;
   constexpr int NB1 = BN >= 128 ? 2 : 1;   // buffers of the fused 1x1 phase (see conv_bf3_kernel: the 64-wide tile keeps its third workgroup per CU)
   constexpr size_t skip_b = SKIP ? (size_t)(2 * NB1 * TH * TW * 40 + NB1 * 8 * BN * 8) * 2 : 0;
@@ -84,7 +95,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   constexpr int NW = TOTW / NT;
   constexpr int TAPS = KS * KS;
   constexpr int NABUF = (KS == 1) ? 2 : 1;
-  constexpr int WRING = (KS == 3) ? 3 : 2;   // W tile buffers (3x3: direct-to-LDS ring of 3; the 4-tap folded conv: ring of 2)
+  constexpr int WRING = conv_bf3_wring<KS, KG>();   // W tile buffers (3x3: direct-to-LDS ring of 3, deeper for KG == 2; the 4-tap folded conv: ring of 2)
   constexpr int WM = BM / NWM, WN = BN / 2;
   constexpr int FM = WM / 32, FN = WN / 32;
   constexpr int PAD = (KS == 3) ? 1 : 0;   // KS == 2 (parity-folded upsampling conv): the pad depends on the parity, see iy0
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x / NT);   // wave group (K half), wave-uniform
-  unsigned char* smem_raw = smem_all + kg * conv_bf3_group_lds<KS, STRIDE, TH, TW, BN, SKIP>();
+  unsigned char* smem_raw = smem_all + kg * conv_bf3_group_lds<KS, STRIDE, TH, TW, BN, SKIP, KG>();
   __bf16* sAh = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* sAl = sAh + APLANE;
   __bf16* sW = sAl + APLANE;               // [WRING bufs][4 k8][2 planes][BN][8]
@@ -346,7 +357,10 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     // One barrier per tap.  At a chunk boundary the halo buffer is rewritten right after the barrier of tap 8 (every wave
     // holds its last A fragments by then) and a second barrier publishes it before the next chunk's A fragments are read.
     constexpr int NS = BK / 16;
-    static_assert(NS == 2 && WRING >= 2 && WRING <= TAPS && TAPS % WRING == 0, "pipeline is written for two K steps per tap and a ring that divides the taps");
+    static_assert(NS == 2 && WRING >= 2 && WRING <= TAPS, "pipeline is written for two K steps per tap and a ring no deeper than a chunk's taps");
+    // DYN: the ring does not divide the taps, so a tile's slot is not a function of its tap alone: the current / next slot's byte
+    // offsets live in SGPRs (rs_cur / rs_nxt, advanced once per tap) and are added to the weight base register (one VALU op per tap)
+    constexpr bool DYN = TAPS % WRING != 0;
     constexpr int NAL = NA + (PRO != 0 ? 2 : 0);   // vector loads issued by loadA (all unconditional)
 #pragma unroll
     for (int d = 0; d < WRING; ++d) gldsW(0, d, d);
@@ -366,13 +380,14 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     const unsigned wb = (unsigned)(size_t)(__attribute__((address_space(3))) __bf16*)(sW + wbase);
     constexpr int ALO = APLANE * 2;          // byte offset of the lo plane
     constexpr int WSLOT = TOTW * 16;         // bytes per ring slot
-    static_assert(ALO + (2 * RP + 2 * PITCH) * 2 + 64 < 65536 && WRING * WSLOT < 65536, "LDS immediates must fit 16 bits");
+    static_assert(ALO + (2 * RP + 2 * PITCH) * 2 + 64 < 65536 && (DYN ? 1 : WRING) * WSLOT < 65536, "LDS immediates must fit 16 bits");
     // AOFF = halo pixel offset of a tap (elements), S = K step inside the tap, SLOT = ring slot
     // single-fragment reads (I = fragment index); the *_ALL forms read a whole operand set
 #define LD_AL1(I, AOFF, S) al[I] = lds_read128<ALO + ((AOFF) + (S) * 16) * 2>(abase[I])
 #define LD_AH1(I, AOFF, S) ah[I] = lds_read128<((AOFF) + (S) * 16) * 2>(abase[I])
-#define LD_BH1(I, SLOT, S) bh[I] = lds_read128<(SLOT) * WSLOT + ((4 * (S)) * BN + (I) * 32) * 16>(wb)
-#define LD_BL1(I, SLOT, S) bl[I] = lds_read128<(SLOT) * WSLOT + ((4 * (S) + 1) * BN + (I) * 32) * 16>(wb)
+    // SLOT: `cur` / `nxt` - the ring slot of this tap's / the next tap's tile (immediate offset, or - DYN - a base register of its own)
+#define LD_BH1(I, SLOT, S) bh[I] = lds_read128<(DYN ? 0 : slot_##SLOT * WSLOT) + ((4 * (S)) * BN + (I) * 32) * 16>(DYN ? wb_##SLOT : wb)
+#define LD_BL1(I, SLOT, S) bl[I] = lds_read128<(DYN ? 0 : slot_##SLOT * WSLOT) + ((4 * (S) + 1) * BN + (I) * 32) * 16>(DYN ? wb_##SLOT : wb)
 #define LD_AL(AOFF, S) static_for<0, FM>([&](auto i) { LD_AL1(i.value, AOFF, S); })
 #define LD_AH(AOFF, S) static_for<0, FM>([&](auto i) { LD_AH1(i.value, AOFF, S); })
 #define LD_BH(SLOT, S) static_for<0, FN>([&](auto i) { LD_BH1(i.value, SLOT, S); })
@@ -436,7 +451,13 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw0 + toff + (size_t)j * (NT / (2 * BN)) * wrow),
                                        (__attribute__((address_space(3))) void*)l, 16, 0, 0);
     };
-    LD_AL(0, 0); LD_BH(0, 0); LD_AH(0, 0); LD_BL(0, 0);
+    int rs_cur = 0;                     // DYN: ring slot of the current tap's tile (wave-uniform)
+    {
+      constexpr int slot_cur = 0;
+      const unsigned wb_cur = wb;
+      (void)slot_cur; (void)wb_cur;
+      LD_AL(0, 0); LD_BH(cur, 0); LD_AH(0, 0); LD_BL(cur, 0);
+    }
     // The loop body is branch-free around the MFMAs (tail iterations prefetch clamped tiles and read fragments that are
     // never used).  LDS reads complete in issue order and are issued in the fixed order a_lo, w_hi, a_hi, w_lo (each set right
     // after its last reader), so "at most FM+FN reads outstanding" is the wait before every group in the steady state.
@@ -447,7 +468,11 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
         constexpr int tap = decltype(tapc)::value;
         constexpr int aoff = (tap / KS) * RP + (tap % KS) * PITCH;
         constexpr int aoff1 = ((tap + 1) / KS) * RP + ((tap + 1) % KS) * PITCH;
-        constexpr int slot = tap % WRING, slotn = (tap + 1) % WRING;   // TAPS % WRING == 0: a tile's ring slot is tap % WRING
+        constexpr int slot_cur = DYN ? 0 : tap % WRING, slot_nxt = DYN ? 0 : (tap + 1) % WRING;   // TAPS % WRING == 0: a tile's ring slot is tap % WRING
+        const int rs_nxt = rs_cur + 1 == WRING ? 0 : rs_cur + 1;
+        const int slot = DYN ? rs_cur : slot_cur;                        // ring slot refilled by this tap (runtime in DYN mode)
+        const unsigned wb_cur = wb + (unsigned)rs_cur * WSLOT, wb_nxt = wb + (unsigned)rs_nxt * WSLOT;
+        (void)wb_cur; (void)wb_nxt; (void)slot_nxt;
         // which halo piece this tap transforms (spread over the middle taps: 2..7 of 9, 1..2 of 4), -1 = none
         constexpr int T0 = TAPS >= 9 ? 2 : 1, TSPAN = TAPS - 1 - T0;
         // filler after MFMA number k of the tap (k = 0..6G-1: groups X0 Z0 Y0 X1 | barrier | Z1 Y1)
@@ -466,8 +491,8 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
               // first use of the halo registers in this chunk: the loads issued in tap 0 are older than the WRING-1 weight tiles
               // issued since (tap T0's own refill comes after this group).  Unconditional - also in the last chunk, whose halo
               // loads are never consumed - so that every path to a transform step passes the wait (tools/lint_asm.py checks it).
-              static_assert(T0 + 1 == WRING, "the count below assumes WRING-1 tiles were issued between tap 0 and tap T0");
-              asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WRING - 1) * NW) : "memory");
+              // (one refill per tap since then: after the barriers of taps 0 .. T0-1)
+              asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T0 * NW) : "memory");
               SB();
             }
             if (has_next) {
@@ -499,13 +524,13 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
         });
         lgkm_wait<(tap == 0) ? FM : FM + FN>(); SB();
         GZ([&](auto fm, auto fn) {
-          if constexpr (fm.value == FM - 1) LD_BH1(fn.value, slot, 1);
+          if constexpr (fm.value == FM - 1) LD_BH1(fn.value, cur, 1);
           filler(std::integral_constant<int, 1 * G + fn.value * FM + fm.value>{});
         });
         lgkm_wait<FM + FN>(); SB();
         GY([&](auto fm, auto fn) {
           if constexpr (fn.value == FN - 1) LD_AH1(fm.value, aoff, 1);
-          if constexpr (fm.value == FM - 1 && fn.value == FN - 1) LD_BL(slot, 1);
+          if constexpr (fm.value == FM - 1 && fn.value == FN - 1) LD_BL(cur, 1);
           filler(std::integral_constant<int, 2 * G + fm.value * FN + fn.value>{});
         });
         lgkm_wait<FM + FN>(); SB();
@@ -524,11 +549,11 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
           if (has_next) writeA(0);
           SB();
           GZ([&](auto fm, auto fn) {
-            if constexpr (fm.value == FM - 1) LD_BH1(fn.value, slotn, 0);
+            if constexpr (fm.value == FM - 1) LD_BH1(fn.value, nxt, 0);
             filler(std::integral_constant<int, 4 * G + fn.value * FM + fm.value>{});
           });
           GY([&](auto fm, auto fn) {
-            if constexpr (fm.value == FM - 1 && fn.value == FN - 1) LD_BL(slotn, 0);
+            if constexpr (fm.value == FM - 1 && fn.value == FN - 1) LD_BL(nxt, 0);
             filler(std::integral_constant<int, 5 * G + fm.value * FN + fn.value>{});
           });
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -539,15 +564,16 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
           // the A reads of the next tap do not depend on the barrier but keep the fixed issue order a_lo, w_hi, a_hi, w_lo
           GZ([&](auto fm, auto fn) {
             if constexpr (fn.value == 0) LD_AL1(fm.value, aoff1, 0);
-            if constexpr (fm.value == FM - 1) LD_BH1(fn.value, slotn, 0);
+            if constexpr (fm.value == FM - 1) LD_BH1(fn.value, nxt, 0);
             filler(std::integral_constant<int, 4 * G + fn.value * FM + fm.value>{});
           });
           GY([&](auto fm, auto fn) {
             if constexpr (fn.value == FN - 1) LD_AH1(fm.value, aoff1, 0);
-            if constexpr (fm.value == FM - 1 && fn.value == FN - 1) LD_BL(slotn, 0);
+            if constexpr (fm.value == FM - 1 && fn.value == FN - 1) LD_BL(nxt, 0);
             filler(std::integral_constant<int, 5 * G + fm.value * FN + fn.value>{});
           });
         }
+        rs_cur = rs_nxt;
       });
     }
 #undef LD_AL1
@@ -706,6 +732,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
 __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __restrict__ part, int S, int M, int N, int hw,
                                                             const float* __restrict__ bias, const float* __restrict__ bias2,
                                                             const float* __restrict__ sbias, int ld_sb,
+                                                            const long long* __restrict__ sb_rows, int sb_nrows,
                                                             const float* __restrict__ res, int ld_res, float* __restrict__ out,
                                                             int ld_out, float* __restrict__ stats) {
   __shared__ float red[16][64][2];
@@ -716,7 +743,9 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
     const int n = blockIdx.y * 64 + c;
     float s1 = 0.f, s2 = 0.f;
     if (n < N) {
-      const float cb = (bias ? bias[n] : 0.f) + (bias2 ? bias2[n] : 0.f) + (sbias ? sbias[(size_t)b * ld_sb + n] : 0.f);
+      long long sr = b;
+      if (sb_rows) { sr = sb_rows[b]; sr = sr < 0 ? 0 : (sr >= sb_nrows ? sb_nrows - 1 : sr); }
+      const float cb = (bias ? bias[n] : 0.f) + (bias2 ? bias2[n] : 0.f) + (sbias ? sbias[(size_t)sr * ld_sb + n] : 0.f);
       for (int i = 0; i < 4; ++i) {
         const size_t m = row0 + rg + 16 * i;
         float v = cb;
@@ -744,7 +773,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
 template <int KS, int STRIDE, bool UPS, int TH, int TW, int BN, int PRO, int NWM = 2, bool SKIP = false, int KG = 1>
 static int launch3_cfg(ConvP& p, hipStream_t stream) {
   constexpr int FMFN = (TH * TW / NWM / 32) * (BN / 2 / 32);
-  constexpr size_t lds_groups = KG * conv_bf3_group_lds<KS, STRIDE, TH, TW, BN, SKIP>();
+  constexpr size_t lds_groups = KG * conv_bf3_group_lds<KS, STRIDE, TH, TW, BN, SKIP, KG>();
   constexpr size_t lds_xch = KG == 2 ? (size_t)FMFN * 16 * NWM * 128 * 4 : 0;   // accumulator hand-over between the wave groups
   constexpr size_t lds = lds_groups > lds_xch ? lds_groups : lds_xch;
   static_assert(lds <= 160 * 1024, "LDS budget");
@@ -753,11 +782,8 @@ static int launch3_cfg(ConvP& p, hipStream_t stream) {
   p.nt = cdiv(p.Npad, BN);
   conv_fill_divs(p);
   auto kern = conv_bf3_kernel<KS, STRIDE, UPS, TH, TW, BN, PRO, NWM, SKIP, KG>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = set_max_lds_once(reinterpret_cast<const void*>(kern), (int)lds, attr_done)) return rc;
   const int grid = p.B * p.tiles_y * p.tiles_x * p.nt * p.ksplit * (KS == 2 ? 4 : 1);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(KG * NWM * 128), lds, stream, p);
   PF_CHECK_HIP(hipGetLastError());
@@ -808,6 +834,7 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   p.w = a.w; p.N = a.n; p.Npad = (a.n + 63) / 64 * 64;
   p.sc = a.sc; p.sh = a.sh; p.mean = a.mean; p.rstd = a.rstd;
   p.bias = a.bias; p.sbias = a.sbias; p.ld_sbias = a.ld_sbias; p.res = a.res; p.ld_res = a.ld_res;
+  p.sb_rows = reinterpret_cast<const long long*>(a.sbias_rows); p.sb_nrows = a.sbias_nrows;
   p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out;
   p.ksplit = conv_ksplit(a);
   p.partial = p.ksplit > 1 ? static_cast<float*>(a.splitk_ws) : nullptr;
@@ -834,7 +861,7 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   if (rc != PF_OK || p.ksplit == 1) return rc;
   const int M = p.B * p.Hout * p.Wout;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M / 64, cdiv(p.N, 64)), dim3(1024), 0, stream, static_cast<const float*>(a.splitk_ws), p.ksplit, M, p.N,
-                     p.Hout * p.Wout, p.bias, p.bias2, p.sbias, p.ld_sbias, p.res, p.ld_res, p.out, p.ld_out, p.stats);
+                     p.Hout * p.Wout, p.bias, p.bias2, p.sbias, p.ld_sbias, p.sb_rows, p.sb_nrows, p.res, p.ld_res, p.out, p.ld_out, p.stats);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }

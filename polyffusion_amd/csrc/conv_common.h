@@ -50,6 +50,7 @@ struct ConvP {
   const void* w; int N, Npad;
   const float* sc; const float* sh; const float* mean; const float* rstd;
   const float* bias; const float* sbias; int ld_sbias; const float* res; int ld_res;
+  const long long* sb_rows; int sb_nrows;   // optional: sample b reads row clamp(sb_rows[b]) of sbias (hoisted time-bias table indexed by t[b])
   int geglu;
   float* out; int ld_out;
   float* stats;   // optional [B][tiles][N][2]: per-tile, per-channel (sum, sum of squares) of the stored outputs
@@ -127,6 +128,13 @@ __device__ __forceinline__ float erf_as_f(float x) {
 __device__ __forceinline__ float gelu_erf_f(float g) { return 0.5f * g * (1.0f + erf_as_f(g * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ void store_out(const ConvP& p, size_t idx, float v) { p.out[idx] = v; }
+// this sample's row of the per-sample bias (nullptr: none)
+__device__ __forceinline__ const float* sbias_row(const ConvP& p, int b) {
+  if (!p.sbias) return nullptr;
+  long long r = b;
+  if (p.sb_rows) { r = p.sb_rows[b]; r = r < 0 ? 0 : (r >= p.sb_nrows ? p.sb_nrows - 1 : r); }
+  return p.sbias + (size_t)r * p.ld_sbias;
+}
 // flat output pixel index of tile pixel (oy, ox) of sample b
 __device__ __forceinline__ size_t out_pixel(const ConvP& p, int b, int oy, int ox) {
   if (p.fold) return ((size_t)b * (2 * p.Hout) + 2 * oy + p.fold_py) * (size_t)(2 * p.Wout) + 2 * ox + p.fold_px;
@@ -204,7 +212,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
     }
   }
   if constexpr (TH == 1) if (pq) {   // linear layers only: keeps this path's registers out of the 3x3 kernels' budget
-    const float* sb = (p.sbias && !p.qkv) ? p.sbias + (size_t)b * p.ld_sbias : nullptr;
+    const float* sb = p.qkv ? nullptr : sbias_row(p, b);
     const float* resp = p.qkv ? nullptr : p.res;
     // hi/lo plane output (linear layers only, TH == 1): the finished tile is transposed through LDS as fp32 so that the
     // split and the global stores run row-wise - 16 bytes per lane per plane, whole 128-byte lines - instead of one 2-byte
@@ -375,7 +383,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
     }
     return;
   }
-  const float* sb = p.sbias ? p.sbias + (size_t)b * p.ld_sbias : nullptr;
+  const float* sb = sbias_row(p, b);
   const bool full = (oy0 + TH <= p.Hout) && (ox0 + TW <= p.Wout) && (n0 + BN <= p.N) && !p.geglu;
   float ssum[FN], ssq[FN];
 #pragma unroll

@@ -219,11 +219,8 @@ static int launch_cfg(ConvP& p, hipStream_t stream) {
   p.tiles_y = cdiv(p.Hout, TH);
   p.nt = cdiv(p.Npad, BN);
   auto kern = conv_mfma_kernel<KS, STRIDE, UPS, TH, TW, BN, BK, PRO>;
-  static bool attr_done = false;  // raise the dynamic-LDS cap once per instantiation
-  if (!attr_done) {
-    PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};  // raise the dynamic-LDS cap once per instantiation and device
+  if (int rc = set_max_lds_once(reinterpret_cast<const void*>(kern), (int)lds, attr_done)) return rc;
   const int grid = p.B * p.tiles_y * p.tiles_x * p.nt;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
   PF_CHECK_HIP(hipGetLastError());
@@ -249,7 +246,7 @@ int conv_pick_tile(const pf_conv_args& a) {
   // bf16x3 3x3 with 64 output channels in all (the 128x128 level): a 16x16-pixel tile when that still gives every CU two rounds of
   // two workgroups - each wave then owns 128 pixels x 32 channels (four A fragments per weight fragment instead of two)
   if (a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.stride == 1 && !a.ups && !a.ups_fold && npad == 64 && hout % 16 == 0 && wout % 16 == 0 &&
-      a.batch * (hout / 16) * (wout / 16) >= 1024 && !a.skip_w && a.c0 + a.c1 >= 128 && !getenv("PF_CONV_NO_T16")) return 3;
+      a.batch * (hout / 16) * (wout / 16) >= 1024 && !a.skip_w && a.c0 + a.c1 >= 128 && !a.no_t16) return 3;
   // (the same 16x16-pixel footprint for the 128-channel tile - 128 x 64 per wave, one workgroup per CU - measured worse at the 64x64
   // level: r64_128_128 55.3 -> 57 us, the fused-skip form 79 -> 82, only the K = 3456 conv gained 2.5 %)
   const bool wide_at_256 = a.precision == PF_PREC_BF16X3 && (a.ks == 3 || a.a_planes);
@@ -371,6 +368,7 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
   p.w = a.w; p.N = a.n; p.Npad = (a.n + 63) / 64 * 64;
   p.sc = a.sc; p.sh = a.sh; p.mean = a.mean; p.rstd = a.rstd;
   p.bias = a.bias; p.sbias = a.sbias; p.ld_sbias = a.ld_sbias; p.res = a.res; p.ld_res = a.ld_res;
+  p.sb_rows = reinterpret_cast<const long long*>(a.sbias_rows); p.sb_nrows = a.sbias_nrows;
   p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out;
   p.ksplit = 1; p.partial = nullptr; p.qkv = a.qkv_planes; p.out_planes = a.out_planes;
 

@@ -178,8 +178,8 @@ static int launch_gp(ConvP& p, hipStream_t stream) {
   p.tiles_x = cdiv(p.Wout, BM); p.tiles_y = 1; p.nt = cdiv(p.Npad, BN);
   conv_fill_divs(p);
   auto kern = gemm_planes_kernel<BM, BN, RING>;
-  static bool done = false;
-  if (!done) { PF_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = set_max_lds_once(reinterpret_cast<const void*>(kern), (int)lds, attr_done)) return rc;
   hipLaunchKernelGGL(kern, dim3(p.B * p.tiles_x * p.nt), dim3(256), lds, stream, p);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
@@ -192,6 +192,7 @@ int launch_gemm_planes(const pf_conv_args& a, hipStream_t stream) {
   p.x0 = a.x0; p.c0 = a.c0; p.B = a.batch; p.Hin = 1; p.Win = a.win; p.Hout = 1; p.Wout = a.win;
   p.w = a.w; p.N = a.n; p.Npad = (a.n + 63) / 64 * 64;
   p.bias = a.bias; p.sbias = a.sbias; p.ld_sbias = a.ld_sbias; p.res = a.res; p.ld_res = a.ld_res;
+  p.sb_rows = reinterpret_cast<const long long*>(a.sbias_rows); p.sb_nrows = a.sbias_nrows;
   p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out; p.out_planes = a.out_planes; p.qkv = a.qkv_planes;
   p.ksplit = 1;
   const int tile = conv_pick_tile(a);

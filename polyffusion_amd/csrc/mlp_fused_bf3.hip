@@ -24,15 +24,11 @@ struct MlpX {
   // one more 256 x 256 projection; ConvP then describes THAT projection's epilogue (bias, block input as residual, statistics)
   const float* b2;                      // ff.net.2 bias (the ff residual is p.x0, the LayerNorm input)
   const __bf16* w3;                     // proj_out: bf16x3 packing [32][plane][256][8]
-  // HEAD (attn1's to_out chained in front, unet_attention.py:210-212 + the residual of :115): the LayerNorm input is computed here,
-  //   x1 = a0 . W0 + b0 + sbias0[sample] + res0,   a0 = the attention output as bf16 hi/lo planes [M][256] | [M][256];
-  // it is also stored to p.x0's buffer (x1out) because the ff residual / the epilogue read it back
-  const __bf16* a0; const __bf16* w0; const float* b0; const float* sbias0; int ld_sbias0; const float* res0; float* x1out;
 };
 
 typedef __bf16 bf16x4_m __attribute__((ext_vector_type(4)));
 
-template <int RING, bool TAIL, bool HEAD>
+template <int RING, bool TAIL>
 __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
   constexpr int BM = 64, C = 256, HID = 1024, HS = 64, NSL = HID / HS;
   constexpr int A_B = BM * C * 4;           // 64 KB: LayerNorm planes, [chunk 8][plane 2][row 64][64 B]
@@ -83,7 +79,6 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
   for (int i = tid; i < 2 * HID; i += 256) sB1[i] = e.b1[i];
 
   // ---- LayerNorm of the tile into the resident planes (one wave per row, arithmetic of ln_planes_kernel) ---------------
-  // rows come from global memory, or (HEAD) from the fp32 tile the chained to_out epilogue left in sA - which the planes then overwrite
   auto layer_norm_tile = [&]() {
     const f32x4 g = *reinterpret_cast<const f32x4*>(e.gamma + lane * 4), be = *reinterpret_cast<const f32x4*>(e.beta + lane * 4);
     constexpr int RPW = BM / 4;   // rows per wave
@@ -91,10 +86,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
     float red[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
-      if constexpr (HEAD) v[i] = *reinterpret_cast<const f32x4*>(sA + (size_t)(wave * RPW + i) * (C * 4) + lane * 16);
-      else v[i] = *reinterpret_cast<const f32x4*>(p.x0 + (row0 + wave * RPW + i) * C + lane * 4);
+      v[i] = *reinterpret_cast<const f32x4*>(p.x0 + (row0 + wave * RPW + i) * C + lane * 4);
     }
-    if constexpr (HEAD) __syncthreads();   // every row is in registers before the first plane store lands on it
     // same arithmetic as ln_planes_kernel (xor butterfly 32, 16, .., 1), but the 16 rows' reductions advance together: a
     // cross-lane move has ~60 cycles of latency and a row needs twelve of them in sequence
 #pragma unroll
@@ -327,78 +320,10 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
     }
   };
 
-  if constexpr (HEAD) {
-    // ---- H: attention output planes -> sA, then 16 steps against to_out's weights; H13..H15 already fetch P0..P2 ----
-    const __bf16* g0 = e.w0 + (size_t)tid * 8;
-    const size_t MK = (size_t)p.B * L * C;
 #pragma unroll
-    for (int cch = 0; cch < 8; ++cch)
+  for (int d = 0; d < RING - 1; ++d)
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int u = tid + jj * 256, plane = u >> 8, w = u & 255, row = w >> 2, slot = w & 3;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(e.a0 + (size_t)plane * MK + (row0 + row) * C + cch * 32 + ((slot ^ ((row >> 2) & 3)) * 8)),
-            (__attribute__((address_space(3))) void*)(sA + cch * CH_B + (wave * 64 + jj * 256) * 16), 16, 0, 0);
-      }
-#pragma unroll
-    for (int d = 0; d < RING - 1; ++d)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) issue_wn(g0, d, d, q);
-    SB();
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 2) * 4) : "memory");   // the planes and H0 have landed
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    SB();
-    static_for<0, 16>([&](auto cc) {
-      auto dma = [&](auto, auto q_) {
-        constexpr int t = decltype(cc)::value + 3, q = decltype(q_)::value;
-        if constexpr (t < 16) issue_wn(g0, t, t % RING, q); else issue_w1(0, t - 16, t % RING, q);
-      };
-      if constexpr (cc.value < 15) ff2_slot(cc, IC(0), dma, no_extra, FROM_A, OPEN_B); else ff2_slot(cc, IC(3), dma, no_extra, FROM_A, OPEN_B);
-    });
-    // x1 = (acc + (b0 + sbias0)) + res0 (conv_epilogue's order): to global (the ff residual reads it back) and, as an fp32 tile, to sA
-    {
-      const int cq = (lane & 31) & ~3;
-      const float* sb = e.sbias0 ? e.sbias0 + (size_t)b * e.ld_sbias0 : nullptr;
-      f32x4 cb4[4];
-#pragma unroll
-      for (int fn = 0; fn < 4; ++fn) {
-        const int n = wn * 128 + fn * 32 + cq;
-        cb4[fn] = f32x4{0.f, 0.f, 0.f, 0.f};
-        cb4[fn] += *reinterpret_cast<const f32x4*>(e.b0 + n);
-        if (sb) cb4[fn] += *reinterpret_cast<const f32x4*>(sb + n);
-      }
-      __syncthreads();   // every wave has finished reading the attention planes
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = wm * 32 + 8 * q + 4 * (lane >> 5) + (lane & 3);
-        f32x4 rr[4];
-#pragma unroll
-        for (int fn = 0; fn < 4; ++fn) rr[fn] = *reinterpret_cast<const f32x4*>(e.res0 + (row0 + row) * C + wn * 128 + fn * 32 + cq);
-#pragma unroll
-        for (int fn = 0; fn < 4; ++fn) {
-          f32x4 v = {acc2[0][fn][4 * q], acc2[0][fn][4 * q + 1], acc2[0][fn][4 * q + 2], acc2[0][fn][4 * q + 3]};
-          quad_transpose(v, lane);
-          v += cb4[fn];
-          v += rr[fn];
-          const int n = wn * 128 + fn * 32 + cq;
-          *reinterpret_cast<f32x4*>(e.x1out + (row0 + row) * C + n) = v;
-          *reinterpret_cast<f32x4*>(sA + (size_t)row * (C * 4) + n * 4) = v;
-        }
-      }
-#pragma unroll
-      for (int fn = 0; fn < 4; ++fn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[0][fn][r] = 0.f;
-      __threadfence_block();
-      __syncthreads();
-    }
-  } else {
-#pragma unroll
-    for (int d = 0; d < RING - 1; ++d)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) issue_w1(0, d, d, q);
-  }
+    for (int q = 0; q < 4; ++q) issue_w1(0, d, d, q);
   layer_norm_tile();
   SB();
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 2) * 4) : "memory");   // slot P0 landed, LN planes and bias written
@@ -532,14 +457,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
 // x: fp32 [B*L][256] (LayerNorm input AND residual); w1 / w2: bf16x3 packings of ff.net.0.proj (GeGLU-interleaved) and ff.net.2.
 // w3 != nullptr chains the SpatialTransformer's proj_out (bf16x3 packing of the [256][256] 1x1 conv, bias b3) and its residual `res3`
 // (the block input) onto the tile: out = res3 + b3 + W3 . (x + ff(LN(x))), with the per-64-row-tile channel statistics in `stats3`.
-// head != nullptr chains attn1's to_out in front: x is then an OUTPUT buffer, x = a0 . W0 + b0 + sbias0[sample] + res0.
 int launch_mlp_fused(const float* x, int batch, int l, const float* gamma, const float* beta, float eps, const void* w1, const float* b1,
                      const void* w2, const float* b2, float* out, void* out_planes, hipStream_t stream, const void* w3, const float* b3,
-                     const float* res3, float* stats3, const MlpHead* head) {
+                     const float* res3, float* stats3) {
   PF_REQUIRE(x && gamma && beta && w1 && b1 && w2 && b2 && (out || out_planes), "mlp_fused: null argument");
   PF_REQUIRE(batch > 0 && l > 0 && l % 64 == 0, "mlp_fused: rows per sample must be a multiple of 64 (got %d)", l);
   PF_REQUIRE(!w3 || (b3 && res3 && out && !out_planes), "mlp_fused: the chained projection needs its bias, its residual and an fp32 output");
-  PF_REQUIRE(!head || (head->a_planes && head->w && head->bias && head->res), "mlp_fused: the chained to_out needs planes, weight, bias and residual");
   constexpr int RING = 4;
   ConvP p;
   memset(&p, 0, sizeof p);
@@ -551,29 +474,16 @@ int launch_mlp_fused(const float* x, int batch, int l, const float* gamma, const
   p.tiles_x = l / 64; p.tiles_y = 1; p.nt = 1;
   conv_fill_divs(p);
   MlpX e{gamma, beta, eps, static_cast<const __bf16*>(w1), b1, b2, static_cast<const __bf16*>(w3)};
-  if (head) {
-    e.a0 = static_cast<const __bf16*>(head->a_planes); e.w0 = static_cast<const __bf16*>(head->w); e.b0 = head->bias;
-    e.sbias0 = head->sbias; e.ld_sbias0 = head->ld_sbias; e.res0 = head->res; e.x1out = const_cast<float*>(x);
-  }
   constexpr size_t main_b = 65536 + RING * 16384 + 16384 + 8192;
   constexpr size_t epi_b = 65536 + (size_t)64 * (256 + 8) * 4;   // planes output: the fp32 tile is transposed through the ring region
   constexpr size_t lds = main_b > epi_b ? main_b : epi_b;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  const void* kerns[4] = {reinterpret_cast<const void*>(mlp_bf3_kernel<RING, false, false>), reinterpret_cast<const void*>(mlp_bf3_kernel<RING, true, false>),
-                          reinterpret_cast<const void*>(mlp_bf3_kernel<RING, false, true>), reinterpret_cast<const void*>(mlp_bf3_kernel<RING, true, true>)};
-  static bool done = false;
-  if (!done) {
-    for (const void* k : kerns) PF_CHECK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    done = true;
-  }
+  static std::atomic<uint64_t> done_plain{0}, done_tail{0};
+  if (int rc = set_max_lds_once(reinterpret_cast<const void*>(mlp_bf3_kernel<RING, false>), (int)lds, done_plain)) return rc;
+  if (int rc = set_max_lds_once(reinterpret_cast<const void*>(mlp_bf3_kernel<RING, true>), (int)lds, done_tail)) return rc;
   const dim3 grid(batch * (l / 64)), block(256);
-  if (head) {
-    if (w3) hipLaunchKernelGGL((mlp_bf3_kernel<RING, true, true>), grid, block, lds, stream, p, e);
-    else hipLaunchKernelGGL((mlp_bf3_kernel<RING, false, true>), grid, block, lds, stream, p, e);
-  } else {
-    if (w3) hipLaunchKernelGGL((mlp_bf3_kernel<RING, true, false>), grid, block, lds, stream, p, e);
-    else hipLaunchKernelGGL((mlp_bf3_kernel<RING, false, false>), grid, block, lds, stream, p, e);
-  }
+  if (w3) hipLaunchKernelGGL((mlp_bf3_kernel<RING, true>), grid, block, lds, stream, p, e);
+  else hipLaunchKernelGGL((mlp_bf3_kernel<RING, false>), grid, block, lds, stream, p, e);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }

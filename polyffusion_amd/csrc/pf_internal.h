@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <string>
 #include "../../include/pfhip.h"
 
@@ -26,6 +27,20 @@ int set_error(int code, const char* fmt, ...);
   } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device) - a process may
+// drive several GPUs - with one bit per device in a mask owned by the launcher (two racing threads both set it: harmless)
+static inline int set_max_lds_once(const void* kern, int bytes, std::atomic<uint64_t>& done_mask) {
+  int dev = 0;
+  PF_CHECK_HIP(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done_mask.load(std::memory_order_acquire) & bit) return PF_OK;
+  PF_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done_mask.fetch_or(bit, std::memory_order_release);
+  return PF_OK;
+}
+// compute units of the current device (cached per device index; 256 on MI355X)
+int num_cus();
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- launchers implemented in the .hip files (all enqueue on `stream`, never sync) ----
@@ -43,14 +58,13 @@ void pack_upfold_bf3(void* dst, const float* src, int N, int K, int Npad);   // 
 int launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                      int batch, int n_heads, int d_head, int lq, int lk, hipStream_t stream);
 
-int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, hipStream_t stream);
+// form: PF_OPT_AUTO | 0 = 128-query workgroups | 1 = 256-query workgroups (needs l % 256 == 0)
+int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, int form, hipStream_t stream);
 int launch_gemm_planes(const pf_conv_args& a, hipStream_t stream);   // called by launch_conv when a.a_planes
-// attn1's to_out chained in front of the fused feed-forward launch: x1 = a_planes . w + bias + sbias[sample] + res (unet_attention.py:115, 210-212)
-struct MlpHead { const void* a_planes; const void* w; const float* bias; const float* sbias; int ld_sbias; const float* res; };
 // out = x + ff2(GeGLU(ff1(LayerNorm(x)))) for C = 256, hidden 1024, as one launch (mlp_fused_bf3.hip); w1 / w2 = bf16x3 packings
 int launch_mlp_fused(const float* x, int batch, int l, const float* gamma, const float* beta, float eps, const void* w1, const float* b1,
                      const void* w2, const float* b2, float* out, void* out_planes, hipStream_t stream, const void* w3 = nullptr,
-                     const float* b3 = nullptr, const float* res3 = nullptr, float* stats3 = nullptr, const MlpHead* head = nullptr);
+                     const float* b3 = nullptr, const float* res3 = nullptr, float* stats3 = nullptr);
 
 size_t gn_scratch_bytes(int batch, int c, int hw);
 int launch_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batch, int hw, int groups, float eps,
@@ -69,10 +83,11 @@ int launch_ln_planes(const float* x, int rows, int c, float eps, const float* ga
 int launch_conv_in(const float* x_nchw, const float* w /*[Cout][Cin][3][3]*/, const float* bias, float* out_nhwc,
                    int batch, int cin, int cout, int h, int w_, hipStream_t stream, float* stats = nullptr);
 int launch_conv_in_stats_tiles(int cin, int cout, int h, int w_);   // per-sample statistics tiles launch_conv_in can emit (0: none)
-int launch_conv_out(const float* x_nhwc, const float* sc, const float* sh, const float* w /*[Cout][9][Cin]*/,
+int launch_conv_out(const float* x_nhwc, const float* sc, const float* sh, const float* w /*[9][Cin][Cout]*/,
                     const float* bias, float* out_nchw, int batch, int cin, int cout, int h, int w_, hipStream_t stream);
 
 // time embedding: t[B] -> silu(time_embed(sinusoid(t))) [B][d_t]
+// t == nullptr: row b is the embedding of time-step value b (the hoisted table of pf_unet_prepare_time)
 int launch_time_embed(const int64_t* t, const float* w0, const float* b0, const float* w2, const float* b2,
                       float* out_silu, int batch, int channels, int d_t, hipStream_t stream);
 // y[b][n] = sum_k W[n][k] * x[b][k] + bias[n]   (row-major W [N][K]; one wave per output)
@@ -94,6 +109,14 @@ int launch_ddpm_step_dev(const float* x, const float* eps, const float* noise_p,
                          const float* mask, const pf_ddpm_coef* table, const pf_step_state* st, float* out, size_t n, hipStream_t s);
 int launch_ddim_step_dev(const float* x, const float* eps, const float* noise, const float* orig, const float* orig_noise,
                          const float* mask, const pf_ddim_coef* table, const pf_step_state* st, float* out, size_t n, hipStream_t s);
+// in-kernel Philox noise (draw indices by value, or - st != nullptr - from the device step state)
+int launch_ddpm_step_rng(const float* x, const float* eps, const float* orig, const float* mask, const pf_ddpm_coef* c_host,
+                         const pf_ddpm_coef* table, const pf_step_state* st, uint64_t seed, uint64_t draw_q, uint64_t draw_p, uint64_t off,
+                         float* out, size_t n, hipStream_t s);
+int launch_ddim_step_rng(const float* x, const float* eps, const float* orig, const float* orig_noise, const float* mask,
+                         const pf_ddim_coef* c_host, const pf_ddim_coef* table, const pf_step_state* st, uint64_t seed, uint64_t draw,
+                         uint64_t off, float* out, size_t n, hipStream_t s);
+int launch_clock_probe(unsigned long long* out2, hipStream_t s);
 int launch_step_state_set(pf_step_state* st, int64_t index, uint64_t draws, hipStream_t s);
 int launch_step_begin(const pf_step_state* st, const int* time_steps, int64_t* t_out, int batch, hipStream_t s);
 int launch_step_end(pf_step_state* st, int draws_used, hipStream_t s);

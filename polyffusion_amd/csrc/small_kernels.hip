@@ -9,6 +9,18 @@
 
 namespace pf {
 
+int num_cus() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int v = cache[dev & 63].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cache[dev & 63].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
 __device__ __forceinline__ float silu_s(float v) { return v / (1.0f + __expf(-v)); }
 
 // ------------------------------------------------------------------ stem conv (Cin tiny)
@@ -141,17 +153,23 @@ int launch_conv_in(const float* x, const float* w, const float* bias, float* out
 }
 
 // ------------------------------------------------------------------ head: GN+SiLU -> conv3x3 -> few channels, NCHW out
-// 16x16 output pixels per block; the transformed 18x18 halo is staged in LDS 16 channels at a time.
-// Weights are pre-packed [Cout][9][Cin].
+// HBM-bound by construction (B x H x W x Cin floats in, a few channels out: 67 MB at the bench shape, 0.6 GFLOP), so the job is to keep the
+// memory pipe busy: 16x16 output pixels per block, the normalised + activated 18x18 halo staged in LDS 16 channels at a time, and
+//   * the NEXT chunk's global loads are issued (into registers) before the current chunk's arithmetic, so every block overlaps its own
+//     memory latency instead of leaving that to its neighbours on the CU;
+//   * SiLU with the hardware reciprocal (silu_f of conv_common.h) - an IEEE division per element costs as much as the rest of the transform;
+//   * weights packed [9][Cin][Cout]: a tap's Cout weights of one input channel are adjacent, wave-uniform addresses -> scalar loads, and for
+//     two / four output channels one v_pk_fma_f32 feeds two accumulators (half the VALU instructions of the dot products).
+typedef float f32x2_s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__ x, const float* __restrict__ sc,
                                                        const float* __restrict__ sh, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, int B, int Cin,
                                                        int H, int W) {
-  // The weights are indexed with wave-uniform (compile-time after unrolling) offsets straight from global memory: hipcc turns those
-  // into scalar loads (s_load through the constant cache) and every FMA takes its weight from an SGPR - no LDS copy of the weights
-  // and no broadcast ds_read per FMA quad (the LDS port is what bounded the previous form: 3 ds_read_b128 per 8 FMAs).
-  constexpr int T = 16, TI = T + 2, CK = 16, CP = CK + 4;
+  constexpr int T = 16, TI = T + 2, CK = 16, CP = CK + 4, NPIECE = TI * TI * (CK / 4), NP = (NPIECE + 255) / 256;
+  constexpr int NPAIR = COUT / 2, ODD = COUT & 1;
   __shared__ __attribute__((aligned(16))) float sx[TI * TI * CP];
   const int tid = threadIdx.x;
   const int tilesx = (W + T - 1) / T, tilesy = (H + T - 1) / T;
@@ -160,53 +178,86 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__
   const int ty = bid % tilesy;
   const int b = bid / tilesy;
   const int py = tid / T, px = tid % T;
-  float acc[COUT];
+  // this thread's pieces of a chunk (a piece = four channels of one halo pixel): fixed across the chunks.  256 % 4 == 0, so the
+  // channel quad (tid & 3) - and with it the thread's scale / shift vectors - is the same for all of them.
+  const int c4 = tid & 3;
+  // Loads are unconditional (padding / surplus pieces read the tile's first valid element and are zeroed by a select when staged):
+  // no exec-mask branches between them, all NP loads of a chunk in flight together.
+  unsigned goff[NP];
+  int soff[NP];
+  float keep[NP];                          // 1: a pixel inside the image, 0: conv padding (zeros of the ACTIVATED tensor)
+  const unsigned gsafe = (unsigned)(((b * H + min(ty * T, H - 1)) * W + min(tx * T, W - 1)) * Cin) + c4 * 4;
 #pragma unroll
-  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-  for (int c0 = 0; c0 < Cin; c0 += CK) {
-    __syncthreads();
-    for (int u = tid; u < TI * TI * (CK / 4); u += 256) {
-      const int c4 = u % (CK / 4), pix = u / (CK / 4);
-      const int iy = ty * T + pix / TI - 1, ix = tx * T + pix % TI - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-        v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + iy) * W + ix) * Cin + c0 + c4 * 4);
-        const float4 a = *reinterpret_cast<const float4*>(sc + (size_t)b * Cin + c0 + c4 * 4);
-        const float4 d = *reinterpret_cast<const float4*>(sh + (size_t)b * Cin + c0 + c4 * 4);
-        v.x = silu_s(v.x * a.x + d.x); v.y = silu_s(v.y * a.y + d.y);
-        v.z = silu_s(v.z * a.z + d.z); v.w = silu_s(v.w * a.w + d.w);
-      }
-      *reinterpret_cast<float4*>(sx + pix * CP + c4 * 4) = v;
+  for (int i = 0; i < NP; ++i) {
+    const int u = tid + i * 256, pix = u >> 2;
+    const int iy = ty * T + pix / TI - 1, ix = tx * T + pix % TI - 1;
+    const bool in = u < NPIECE && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    soff[i] = u < NPIECE ? pix * CP + c4 * 4 : -1;
+    goff[i] = in ? (unsigned)(((b * H + iy) * W + ix) * Cin) + c4 * 4 : gsafe;
+    keep[i] = in ? 1.f : 0.f;
+  }
+  f32x4 r[NP], a4, d4;
+  auto load = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) r[i] = *reinterpret_cast<const f32x4*>(x + (size_t)goff[i] + c0);
+    a4 = *reinterpret_cast<const f32x4*>(sc + (size_t)b * Cin + c0 + c4 * 4);
+    d4 = *reinterpret_cast<const f32x4*>(sh + (size_t)b * Cin + c0 + c4 * 4);
+  };
+  auto stage = [&]() {   // normalise + SiLU
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      f32x4 v = r[i] * a4 + d4;
+      v[0] = silu_fast(v[0]) * keep[i]; v[1] = silu_fast(v[1]) * keep[i]; v[2] = silu_fast(v[2]) * keep[i]; v[3] = silu_fast(v[3]) * keep[i];
+      if (soff[i] >= 0) *reinterpret_cast<f32x4*>(sx + soff[i]) = v;
     }
-    __syncthreads();
-    const float* wc = w + c0;   // [COUT][9][Cin], this chunk's 16 channels
+  };
+  f32x2_s acc2[NPAIR > 0 ? NPAIR : 1];
+  float acc1 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+  for (int q = 0; q < NPAIR; ++q) acc2[q] = f32x2_s{0.f, 0.f};
+  load(0);
+  stage();
+  __syncthreads();
+  for (int c0 = 0; c0 < Cin; c0 += CK) {
+    const bool more = c0 + CK < Cin;
+    if (more) load(c0 + CK);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const float* xp = sx + ((py + r) * TI + px + s) * CP;
+    for (int t = 0; t < 9; ++t) {
+      const float* xp = sx + ((py + t / 3) * TI + px + t % 3) * CP;
+      const float* wt = w + (size_t)__builtin_amdgcn_readfirstlane((t * Cin + c0) * COUT);   // [tap][Cin][COUT]: uniform address -> scalar loads
 #pragma unroll
-        for (int c4 = 0; c4 < CK / 4; ++c4) {
-          const float4 v = *reinterpret_cast<const float4*>(xp + c4 * 4);
+      for (int k4 = 0; k4 < CK / 4; ++k4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xp + k4 * 4);
 #pragma unroll
-          for (int co = 0; co < COUT; ++co) {
-            const float* ww = wc + ((size_t)co * 9 + r * 3 + s) * Cin + c4 * 4;   // uniform address -> scalar loads
-            acc[co] = fmaf(v.x, ww[0], acc[co]); acc[co] = fmaf(v.y, ww[1], acc[co]);
-            acc[co] = fmaf(v.z, ww[2], acc[co]); acc[co] = fmaf(v.w, ww[3], acc[co]);
-          }
+        for (int e = 0; e < 4; ++e) {
+          const float* we = wt + (k4 * 4 + e) * COUT;
+#pragma unroll
+          for (int q = 0; q < NPAIR; ++q)
+            acc2[q] = __builtin_elementwise_fma(f32x2_s{v[e], v[e]}, f32x2_s{we[2 * q], we[2 * q + 1]}, acc2[q]);
+          if (ODD) acc1 = fmaf(v[e], we[COUT - 1], acc1);
         }
       }
+    }
+    __syncthreads();            // every thread has finished reading this chunk's image
+    if (more) {
+      stage();
+      __syncthreads();
+    }
   }
   const int oy = ty * T + py, ox = tx * T + px;
   if (oy < H && ox < W) {
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) out[(((size_t)b * COUT + co) * H + oy) * W + ox] = acc[co] + bias[co];
+    for (int co = 0; co < COUT; ++co) {
+      const float a = (ODD && co == COUT - 1) ? acc1 : acc2[co / 2][co & 1];
+      out[(((size_t)b * COUT + co) * H + oy) * W + ox] = a + bias[co];
+    }
   }
 }
 
 int launch_conv_out(const float* x, const float* sc, const float* sh, const float* w, const float* bias, float* out, int batch,
                     int cin, int cout, int h, int w_, hipStream_t stream) {
   PF_REQUIRE(cout >= 1 && cout <= 4 && cin % 16 == 0, "conv_out: unsupported channel counts %d->%d", cin, cout);
+  PF_REQUIRE((size_t)batch * h * w_ * cin < ((size_t)1 << 31), "conv_out: tensor too large for 32-bit element offsets");
   const int grid = batch * cdiv(h, 16) * cdiv(w_, 16);
   switch (cout) {
     case 1: hipLaunchKernelGGL(conv_out_kernel<1>, dim3(grid), dim3(256), 0, stream, x, sc, sh, w, bias, out, batch, cin, h, w_); break;
@@ -257,7 +308,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restri
   float* hbuf = sm + channels;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int half = channels / 2;
-  const float tv = (float)t[b];
+  const float tv = t ? (float)t[b] : (float)b;   // t == nullptr: the table form, row b = time-step value b
   for (int i = tid; i < 2 * half; i += 256) {
     const int j = i % half;
     float a = -9.210340371976184f * (float)j;  // -ln(10000) * j / half, evaluated in fp32 like the reference
@@ -369,12 +420,21 @@ int launch_matvec(const float* x, int ldx, const float* w, const float* bias, fl
 }
 
 // ------------------------------------------------------------------ sampler elementwise kernels
+// Individually rounded fp32 operations the optimiser cannot merge.  __fmul_rn / __fadd_rn are plain * and + in this toolchain (no
+// OCML_BASIC_ROUNDED_OPERATIONS) and `#pragma clang fp contract(off)` does not survive inlining + SLP vectorisation here (the *_step_rng
+// kernels came out with v_pk_fma_f32 where the scalar kernels had separate multiplies and adds: last-bit differences between two
+// kernels that must agree).  One opaque VALU instruction per operation: every kernel that inlines the update computes the same bits,
+// in the reference's operation order (each product rounded, then the sum).
+__device__ __forceinline__ float mul_rn(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float add_rn(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float sub_rn(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 static inline dim3 ew_grid(size_t n) { return dim3((unsigned)min((size_t)2048, (n + 255) / 256)); }
 
 __global__ void cfg_combine_kernel(const float* __restrict__ e2, float s, float* __restrict__ e, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float u = e2[i], c = e2[n + i];
-    e[i] = u + s * (c - u);
+    e[i] = add_rn(u, mul_rn(s, sub_rn(c, u)));   // e_u + s * (e_c - e_u) as three rounded operations, like the reference's tensor ops
   }
 }
 int launch_cfg_combine(const float* eps2, float scale, float* eps, size_t n, hipStream_t s) {
@@ -384,20 +444,25 @@ int launch_cfg_combine(const float* eps2, float scale, float* eps, size_t n, hip
   return PF_OK;
 }
 
-__device__ __forceinline__ float ddpm_update(float xv, float ev, const float* np, const float* nq, const float* orig, const float* mask,
-                                             const pf_ddpm_coef& c, size_t i) {
+// one element of the DDPM / RePaint update on VALUES (has_*: which optional operands take part)
+__device__ __forceinline__ float ddpm_update_v(float xv, float ev, bool has_p, float np, bool has_orig, bool has_q, float nq, float ov, float m,
+                                               const pf_ddpm_coef& c) {
   // same operation order as the reference (each product rounded, then the sum)
-  const float x0 = __fsub_rn(__fmul_rn(c.c_recip, xv), __fmul_rn(c.c_recipm1, ev));
-  const float mean = __fadd_rn(__fmul_rn(c.c_x0, x0), __fmul_rn(c.c_xt, xv));
+  const float x0 = sub_rn(mul_rn(c.c_recip, xv), mul_rn(c.c_recipm1, ev));
+  const float mean = add_rn(mul_rn(c.c_x0, x0), mul_rn(c.c_xt, xv));
   float xu = mean;
-  if (np) xu = __fadd_rn(mean, __fmul_rn(c.sigma, np[i]));
-  if (orig) {
-    float xk = __fmul_rn(c.sqrt_ab, orig[i]);
-    if (nq) xk = __fadd_rn(xk, __fmul_rn(c.sqrt_1mab, nq[i]));
-    const float m = mask[i];
-    xu = __fadd_rn(__fmul_rn(xk, m), __fmul_rn(xu, 1.0f - m));
+  if (has_p) xu = add_rn(mean, mul_rn(c.sigma, np));
+  if (has_orig) {
+    float xk = mul_rn(c.sqrt_ab, ov);
+    if (has_q) xk = add_rn(xk, mul_rn(c.sqrt_1mab, nq));
+    xu = add_rn(mul_rn(xk, m), mul_rn(xu, sub_rn(1.0f, m)));
   }
   return xu;
+}
+__device__ __forceinline__ float ddpm_update(float xv, float ev, const float* np, const float* nq, const float* orig, const float* mask,
+                                             const pf_ddpm_coef& c, size_t i) {
+  return ddpm_update_v(xv, ev, np != nullptr, np ? np[i] : 0.f, orig != nullptr, nq != nullptr, nq ? nq[i] : 0.f, orig ? orig[i] : 0.f,
+                       orig ? mask[i] : 0.f, c);
 }
 __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ np,
                                  const float* __restrict__ nq, const float* __restrict__ orig, const float* __restrict__ mask,
@@ -431,7 +496,7 @@ int launch_ddpm_step(const float* x, const float* eps, const float* noise_p, con
 __global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float a, float b, float* __restrict__ out,
                              size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    out[i] = __fadd_rn(__fmul_rn(a, x[i]), __fmul_rn(b, y[i]));
+    out[i] = add_rn(mul_rn(a, x[i]), mul_rn(b, y[i]));
 }
 int launch_axpby(const float* x, const float* y, float a, float b, float* out, size_t n, hipStream_t s) {
   PF_REQUIRE(x && y && out && n > 0, "axpby: bad arguments");
@@ -440,17 +505,21 @@ int launch_axpby(const float* x, const float* y, float a, float b, float* out, s
   return PF_OK;
 }
 
-__device__ __forceinline__ float ddim_update(float xv, float e, const float* noise, const float* orig, const float* on, const float* mask,
-                                             const pf_ddim_coef& c, size_t i) {
-  const float p0 = __fdiv_rn(__fsub_rn(xv, __fmul_rn(c.s1m, e)), c.sqrt_a);
-  float xp = __fadd_rn(__fmul_rn(c.sqrt_aprev, p0), __fmul_rn(c.dir_coef, e));
-  if (noise) xp = __fadd_rn(xp, __fmul_rn(c.sigma, noise[i]));
-  if (orig) {
-    const float ot = __fadd_rn(__fmul_rn(c.q_sqrt_a, orig[i]), __fmul_rn(c.q_s1m, on[i]));
-    const float m = mask[i];
-    xp = __fadd_rn(__fmul_rn(ot, m), __fmul_rn(xp, 1.0f - m));
+__device__ __forceinline__ float ddim_update_v(float xv, float e, bool has_noise, float nz, bool has_orig, float ov, float onv, float m,
+                                               const pf_ddim_coef& c) {
+  const float p0 = __fdiv_rn(sub_rn(xv, mul_rn(c.s1m, e)), c.sqrt_a);   // (a correctly rounded division has nothing to be merged with)
+  float xp = add_rn(mul_rn(c.sqrt_aprev, p0), mul_rn(c.dir_coef, e));
+  if (has_noise) xp = add_rn(xp, mul_rn(c.sigma, nz));
+  if (has_orig) {
+    const float ot = add_rn(mul_rn(c.q_sqrt_a, ov), mul_rn(c.q_s1m, onv));
+    xp = add_rn(mul_rn(ot, m), mul_rn(xp, sub_rn(1.0f, m)));
   }
   return xp;
+}
+__device__ __forceinline__ float ddim_update(float xv, float e, const float* noise, const float* orig, const float* on, const float* mask,
+                                             const pf_ddim_coef& c, size_t i) {
+  return ddim_update_v(xv, e, noise != nullptr, noise ? noise[i] : 0.f, orig != nullptr, orig ? orig[i] : 0.f, orig ? on[i] : 0.f,
+                       orig ? mask[i] : 0.f, c);
 }
 __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
                                  const float* __restrict__ orig, const float* __restrict__ on, const float* __restrict__ mask,
@@ -513,20 +582,35 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
   const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
   c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
+// the four standard normals of group g (elements 4g .. 4g+3 of the global tensor) of draw `sid`.
+// NOT inlined: randn_kernel and the *_step_rng kernels must produce the same bits for the same (g, sid, seed), and the generated code
+// of logf / sincosf / the products around them depends on its surroundings when inlined (measured: two calls in one kernel differ from
+// the stand-alone kernel in the last bit of ~20 % of the draws) - one shared body is the same arithmetic by construction.
+__device__ __noinline__ f32x4 philox_normal4v(uint64_t g, uint64_t sid, uint64_t seed) {
+#pragma clang fp contract(off)
+  float z[4];
+  uint32_t c0 = (uint32_t)g, c1 = (uint32_t)(g >> 32), c2 = (uint32_t)sid, c3 = (uint32_t)(sid >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+  const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+  float sa, ca, sb, cb;
+  sincosf(6.283185307179586f * u1, &sa, &ca);
+  sincosf(6.283185307179586f * u3, &sb, &cb);
+  z[0] = ra * ca; z[1] = ra * sa; z[2] = rb * cb; z[3] = rb * sb;
+  return f32x4{z[0], z[1], z[2], z[3]};
+}
+__device__ __forceinline__ void philox_normal4(uint64_t g, uint64_t sid, uint64_t seed, float (&z)[4]) {
+  const f32x4 v = philox_normal4v(g, sid, seed);
+  z[0] = v[0]; z[1] = v[1]; z[2] = v[2]; z[3] = v[3];
+}
 __device__ __forceinline__ void randn_body(float* __restrict__ out, size_t n, uint64_t seed, uint64_t sid, uint64_t off) {
   const uint64_t g0 = off >> 2, g1 = (off + n + 3) >> 2;
   for (uint64_t g = g0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < g1; g += (uint64_t)gridDim.x * blockDim.x) {
-    uint32_t c0 = (uint32_t)g, c1 = (uint32_t)(g >> 32), c2 = (uint32_t)sid, c3 = (uint32_t)(sid >> 32);
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) { philox_round(c0, c1, c2, c3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-    const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
-    float sa, ca, sb, cb;
-    sincosf(6.283185307179586f * u1, &sa, &ca);
-    sincosf(6.283185307179586f * u3, &sb, &cb);
-    const float z[4] = {ra * ca, ra * sa, rb * cb, rb * sb};
+    float z[4];
+    philox_normal4(g, sid, seed, z);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint64_t e = g * 4 + j;
@@ -548,6 +632,89 @@ int launch_randn_dev(float* out, size_t n, uint64_t seed, const pf_step_state* s
 int launch_randn(float* out, size_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, hipStream_t s) {
   PF_REQUIRE(out && n > 0, "randn: bad arguments");
   hipLaunchKernelGGL(randn_kernel, ew_grid(n / 4 + 1), dim3(256), 0, s, out, n, seed, stream_id, elem_offset);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+// ---- the sampler updates with the noise drawn in the kernel: a thread owns the four elements of one Philox group, the draws are
+// philox_normal4 of (group, draw index, seed) - exactly what randn_kernel stores for that draw - and the update is ddpm_update /
+// ddim_update on those values: bit-identical to randn + step, without the noise tensors' round trip through HBM
+template <class Coef>
+__device__ __forceinline__ Coef coef_of(const Coef& by_value, const Coef* table, const pf_step_state* st) { return table ? table[st->index] : by_value; }
+__global__ void ddpm_step_rng_kernel(const float* x, const float* __restrict__ eps, const float* __restrict__ orig, const float* __restrict__ mask,
+                                     pf_ddpm_coef cv, const pf_ddpm_coef* __restrict__ table, const pf_step_state* __restrict__ st, uint64_t seed,
+                                     uint64_t draw_q, uint64_t draw_p, uint64_t off, float* out, size_t n) {
+  const pf_ddpm_coef c = coef_of(cv, table, st);
+  if (st) { draw_q = st->draws; draw_p = st->draws + (orig ? 1u : 0u); }
+  const size_t ng = n >> 2;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += (size_t)gridDim.x * blockDim.x) {
+    float zp[4], zq[4] = {0.f, 0.f, 0.f, 0.f};
+    philox_normal4((off >> 2) + g, draw_p, seed, zp);
+    if (orig) philox_normal4((off >> 2) + g, draw_q, seed, zq);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + 4 * g), ev = *reinterpret_cast<const f32x4*>(eps + 4 * g);
+    f32x4 ov = {0.f, 0.f, 0.f, 0.f}, mv = ov, o;
+    if (orig) { ov = *reinterpret_cast<const f32x4*>(orig + 4 * g); mv = *reinterpret_cast<const f32x4*>(mask + 4 * g); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = ddpm_update_v(xv[j], ev[j], true, zp[j], orig != nullptr, orig != nullptr, zq[j], ov[j], mv[j], c);
+    *reinterpret_cast<f32x4*>(out + 4 * g) = o;
+  }
+}
+__global__ void ddim_step_rng_kernel(const float* x, const float* __restrict__ eps, const float* __restrict__ orig, const float* __restrict__ on,
+                                     const float* __restrict__ mask, pf_ddim_coef cv, const pf_ddim_coef* __restrict__ table,
+                                     const pf_step_state* __restrict__ st, uint64_t seed, uint64_t draw, uint64_t off, float* out, size_t n) {
+  const pf_ddim_coef c = coef_of(cv, table, st);
+  if (st) draw = st->draws;
+  const size_t ng = n >> 2;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += (size_t)gridDim.x * blockDim.x) {
+    float z[4];
+    philox_normal4((off >> 2) + g, draw, seed, z);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + 4 * g), ev = *reinterpret_cast<const f32x4*>(eps + 4 * g);
+    f32x4 ov = {0.f, 0.f, 0.f, 0.f}, nv = ov, mv = ov, o;
+    if (orig) { ov = *reinterpret_cast<const f32x4*>(orig + 4 * g); nv = *reinterpret_cast<const f32x4*>(on + 4 * g); mv = *reinterpret_cast<const f32x4*>(mask + 4 * g); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = ddim_update_v(xv[j], ev[j], true, z[j], orig != nullptr, ov[j], nv[j], mv[j], c);
+    *reinterpret_cast<f32x4*>(out + 4 * g) = o;
+  }
+}
+int launch_ddpm_step_rng(const float* x, const float* eps, const float* orig, const float* mask, const pf_ddpm_coef* c_host,
+                         const pf_ddpm_coef* table, const pf_step_state* st, uint64_t seed, uint64_t draw_q, uint64_t draw_p, uint64_t off,
+                         float* out, size_t n, hipStream_t s) {
+  PF_REQUIRE(x && eps && out && n > 0 && (!orig || mask) && (c_host || (table && st)), "ddpm_step_rng: bad arguments");
+  PF_REQUIRE(n % 4 == 0 && off % 4 == 0, "ddpm_step_rng: n and elem_offset must be multiples of 4 (one Philox call yields four normals)");
+  PF_REQUIRE((((uintptr_t)x | (uintptr_t)eps | (uintptr_t)out | (uintptr_t)orig | (uintptr_t)mask) & 15) == 0, "ddpm_step_rng: tensors must be 16-byte aligned");
+  hipLaunchKernelGGL(ddpm_step_rng_kernel, ew_grid(n / 4), dim3(256), 0, s, x, eps, orig, mask, c_host ? *c_host : pf_ddpm_coef{}, c_host ? nullptr : table,
+                     c_host ? nullptr : st, seed, draw_q, draw_p, off, out, n);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+int launch_ddim_step_rng(const float* x, const float* eps, const float* orig, const float* orig_noise, const float* mask,
+                         const pf_ddim_coef* c_host, const pf_ddim_coef* table, const pf_step_state* st, uint64_t seed, uint64_t draw,
+                         uint64_t off, float* out, size_t n, hipStream_t s) {
+  PF_REQUIRE(x && eps && out && n > 0 && (!orig || (mask && orig_noise)) && (c_host || (table && st)), "ddim_step_rng: bad arguments");
+  PF_REQUIRE(n % 4 == 0 && off % 4 == 0, "ddim_step_rng: n and elem_offset must be multiples of 4 (one Philox call yields four normals)");
+  PF_REQUIRE((((uintptr_t)x | (uintptr_t)eps | (uintptr_t)out | (uintptr_t)orig | (uintptr_t)orig_noise | (uintptr_t)mask) & 15) == 0, "ddim_step_rng: tensors must be 16-byte aligned");
+  hipLaunchKernelGGL(ddim_step_rng_kernel, ew_grid(n / 4), dim3(256), 0, s, x, eps, orig, orig_noise, mask, c_host ? *c_host : pf_ddim_coef{},
+                     c_host ? nullptr : table, c_host ? nullptr : st, seed, draw, off, out, n);
+  PF_CHECK_HIP(hipGetLastError());
+  return PF_OK;
+}
+
+// ------------------------------------------------------------------ clock probe
+// {shader-clock counter, constant-rate reference counter} per XCD at the moment the probe runs: two probes bracketing a stretch of
+// stream work give the AVERAGE shader clock of every XCD over it (the part is power-managed: the same binary clocks differently from
+// box to box and under different loads, and the eight XCDs have counters - and clocks - of their own, so a begin / end pair must
+// come from the same XCD).  s_memtime counts shader cycles, s_memrealtime the fixed reference clock (100 MHz on gfx950; bench.py
+// calibrates it against the host clock instead of assuming it).  64 single-wave workgroups are dealt round-robin over the XCDs;
+// each writes row XCC_ID of out[8][2] (several per XCD: the last writer wins, they differ by nanoseconds).
+__global__ void clock_probe_kernel(unsigned long long* out) {
+  if (threadIdx.x != 0) return;
+  const unsigned xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7u;   // bits 3:0 = XCC id
+  out[2 * xcc + 0] = __builtin_amdgcn_s_memtime();
+  out[2 * xcc + 1] = __builtin_amdgcn_s_memrealtime();
+}
+int launch_clock_probe(unsigned long long* out2, hipStream_t s) {
+  PF_REQUIRE(out2, "clock_probe: null output");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(64), dim3(64), 0, s, out2);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }

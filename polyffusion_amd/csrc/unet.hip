@@ -68,6 +68,7 @@ struct pf_unet {
   int cross_cursor = 0;
   size_t cross_o_cursor = 0;
   const float* wdev = nullptr;
+  int opt[PF_OPT_COUNT] = {PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO};   // pf_unet_set_option
   // profiling
   int precision = PF_PREC_F32;
   bool profiling = false;
@@ -351,10 +352,10 @@ static int pack_one(const ParamSpec& ps, const float* src, float* blob) {
         for (int n = 0; n < d.N; ++n) dst[geglu_col(n, inner)] = src[n];
         break;
       }
-      case D_CONVOUT:  // [Cout][Cin][3][3] -> [Cout][9][Cin]
+      case D_CONVOUT:  // [Cout][Cin][3][3] -> [9][Cin][Cout]
         for (int co = 0; co < d.N; ++co)
           for (int ci = 0; ci < d.K; ++ci)
-            for (int t = 0; t < 9; ++t) dst[((size_t)co * 9 + t) * d.K + ci] = src[((size_t)co * d.K + ci) * 9 + t];
+            for (int t = 0; t < 9; ++t) dst[((size_t)t * d.K + ci) * d.N + co] = src[((size_t)co * d.K + ci) * 9 + t];
         break;
     }
   }
@@ -375,6 +376,10 @@ struct Ctx {
   const float* W;
   int n_launch;
   int rc;
+  // hoisted step-invariant prefix (pf_unet_prepared): supplied parts are not recomputed; dry runs only need to know WHETHER they are
+  bool has_time = false, has_cross = false;
+  const float* prep_time = nullptr; int prep_time_rows = 0; const float* prep_cross = nullptr;
+  const int64_t* t_rows = nullptr;   // with a time table: the per-sample row index = t
 
   float* palloc(size_t nfloats) {
     size_t o = persist_off; persist_off += align_up(nfloats * 4, 256);
@@ -408,6 +413,7 @@ struct Ctx {
     const int cin_ = a.c0 + a.c1;
     const bool bf3 = u->precision == PF_PREC_BF16X3 && cin_ % 32 == 0;
     if (bf3) a.precision = PF_PREC_BF16X3;   // decided before the tile (and thus the statistics layout) is chosen
+    a.no_t16 = u->opt[PF_OPT_CONV_T16] == PF_OPT_OFF;
     if (const size_t wsb = conv_splitk_ws_bytes(a)) {   // small-M layer: K-split partial sums live in the temp region
       float* ws = talloc(wsb / 4);
       a.splitk_ws = dry ? (void*)1 : (void*)ws; a.splitk_ws_bytes = wsb;
@@ -495,6 +501,7 @@ static Tn run_res(Ctx& c, const Layer& L, const Tn& x0, const Tn& x1, int H, int
     a.prologue = 1; a.sc = sc1; a.sh = sh1; a.bias = c.w(L.b1);
     c.gn_attach(a, g1);
     a.sbias = c.dry ? nullptr : tb_all + L.emb_off; a.ld_sbias = c.u->sum_emb;
+    a.sbias_rows = c.t_rows; a.sbias_nrows = c.prep_time_rows;   // hoisted table: row = t[b]
     c.conv(a, PF_K_CONV3, &ht, false);
   }
   const Ctx::GnRef g2 = c.gn(ht, Tn{}, hw, 1e-5f, L.gn2_g, L.gn2_b, sc2, sh2, true);
@@ -529,13 +536,12 @@ static Tn run_res(Ctx& c, const Layer& L, const Tn& x0, const Tn& x1, int H, int
 // The fused feed-forward launch (mlp_fused_bf3.hip) gives every 64-row tile to one four-wave workgroup that streams all 3 MB of ff
 // weights and occupies a whole CU (152 KB of LDS), so it runs in rounds of 256 tiles: measured 95 us per round against 113 us per
 // 16384 rows for the three launches it replaces (B = 16, L = 1024).  It is used when the last round is at least 85 % full
-// (B = 16 and B = 32 at the 32x32 level; never at the 16x16 level below B = 55).  PF_MLP_FUSED=0/1 forces it off / on.
-static bool mlp_fused_wanted(int C, int hw, int M) {
-  static const int force = [] { const char* e = getenv("PF_MLP_FUSED"); return e ? atoi(e) : -1; }();
+// (B = 16 and B = 32 at the 32x32 level; never at the 16x16 level below B = 55).  pf_unet_set_option(PF_OPT_MLP_FUSED) forces it off / on.
+static bool mlp_fused_wanted(int C, int hw, int M, int force) {
   if (C != 256 || hw % 64 != 0) return false;
-  if (force >= 0) return force != 0;
-  const int tiles = M / 64, rounds = (tiles + 255) / 256;
-  return tiles * 100 >= 85 * 256 * rounds;
+  if (force != PF_OPT_AUTO) return force != PF_OPT_OFF;
+  const int cus = num_cus(), tiles = M / 64, rounds = (tiles + cus - 1) / cus;
+  return tiles * 100 >= 85 * cus * rounds;
 }
 
 static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const float* cond, const float* cross_all) {
@@ -581,19 +587,12 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
     }
     c.prof_begin(PF_K_ATTN, 4.0 * B * nh * (double)hw * hw * dh);
     if (!c.dry && c.rc == PF_OK)
-      c.rc = planes ? launch_attention_bf3(qkv, nullptr, C, att, B, nh, hw, c.s)   // att as hi/lo planes for the to_out GEMM
+      c.rc = planes ? launch_attention_bf3(qkv, nullptr, C, att, B, nh, hw, c.u->opt[PF_OPT_ATTN_WIDE], c.s)   // att as hi/lo planes for the to_out GEMM
                     : launch_attention(qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, att, C, B, nh, dh, hw, hw, c.s);
     c.prof_end();
     last_planes = planes && (i + 1 == L.tbs.size());
-    const bool fuse_mlp = planes && mlp_fused_wanted(C, hw, M);
-    // to_out can ride in front of the feed-forward launch (pf_transformer_tail_fused; its LayerNorm input is then made on chip).  Measured
-    // at B = 16: neutral end to end (189.0 vs 189.0 steps/s, same box) - the 256 workgroups fetch their attention planes and residual rows (192 KB each) in one un-overlapped
-    // burst and run the 16 extra steps at one wave per SIMD, which costs what the separate two-workgroups-per-CU launch cost.  Off unless
-    // PF_MLP_HEAD=1.
-    static const bool head_on = [] { const char* e = getenv("PF_MLP_HEAD"); return e && atoi(e) != 0; }();
-    const bool fuse_head = head_on && fuse_mlp && c.n_cond == 1;
-    MlpHead head{att, c.w(t.o1w) + (size_t)C * C, c.w(t.o1b), c.dry ? nullptr : cross_all + t.cross_off, c.u->cross_total, t0};
-    if (!fuse_head) {
+    const bool fuse_mlp = planes && mlp_fused_wanted(C, hw, M, c.u->opt[PF_OPT_MLP_FUSED]);
+    {
       pf_conv_args a = conv_base(att, C, nullptr, 0, B, 1, hw, 1, c.w(t.o1w), C, t1);
       a.bias = c.w(t.o1b); a.res = t0; a.ld_res = C; a.a_planes = planes ? 1 : 0;
       if (c.n_cond == 1) {  // x = attn2(LN2(x), c) + x collapses to a per-sample bias (softmax over one key == 1)
@@ -632,21 +631,19 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
         // together with the 64-row-tile statistics the next GroupNorm reads
         const int nt = hw / 64;
         float* sb = c.palloc((size_t)B * nt * C * 2);
-        c.prof_begin(PF_K_GEMM, 2.0 * M * ((double)C * 8 * C + 4.0 * C * C + (double)C * C + (fuse_head ? (double)C * C : 0.0)));
+        c.prof_begin(PF_K_GEMM, 2.0 * M * ((double)C * 8 * C + 4.0 * C * C + (double)C * C));
         if (!c.dry && c.rc == PF_OK)
           c.rc = launch_mlp_fused(t1, B, hw, c.w(t.n3g), c.w(t.n3b), 1e-5f, c.w(t.ff1w) + (size_t)C * 8 * C, c.w(t.ff1b),
-                                  c.w(t.ff2w) + (size_t)4 * C * C, c.w(t.ff2b), out, nullptr, c.s, c.w(L.pout_w) + (size_t)C * C, c.w(L.pout_b), x, sb,
-                                  fuse_head ? &head : nullptr);
+                                  c.w(t.ff2w) + (size_t)4 * C * C, c.w(t.ff2b), out, nullptr, c.s, c.w(L.pout_w) + (size_t)C * C, c.w(L.pout_b), x, sb);
         c.prof_end();
         Tn ot;
         ot.d = out; ot.c = C; ot.st = sb; ot.nt = nt;
         return ot;
       }
-      c.prof_begin(PF_K_GEMM, 2.0 * M * ((double)C * 8 * C + 4.0 * C * C + (fuse_head ? (double)C * C : 0.0)));
+      c.prof_begin(PF_K_GEMM, 2.0 * M * ((double)C * 8 * C + 4.0 * C * C));
       if (!c.dry && c.rc == PF_OK)
         c.rc = launch_mlp_fused(t1, B, hw, c.w(t.n3g), c.w(t.n3b), 1e-5f, c.w(t.ff1w) + (size_t)C * 8 * C, c.w(t.ff1b),
-                                c.w(t.ff2w) + (size_t)4 * C * C, c.w(t.ff2b), t2, nullptr, c.s, nullptr, nullptr, nullptr, nullptr,
-                                fuse_head ? &head : nullptr);
+                                c.w(t.ff2w) + (size_t)4 * C * C, c.w(t.ff2b), t2, nullptr, c.s);
       c.prof_end();
       std::swap(t0, t2);
       continue;
@@ -683,40 +680,55 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
 
 static void small_launch(Ctx& c, int rc_in) { if (c.rc == PF_OK) c.rc = rc_in; }
 
+// n_cond == 1: cross[b] = to_out(to_v(cond[b])) + bias of EVERY transformer block (softmax over one key == 1, unet_attention.py:186-212):
+// two grouped mat-vec launches (one per block when the blocks differ in width).  Shared by the forward plan and pf_unet_prepare_cond.
+static void cross_bias_launches(pf_unet* u, Ctx& c, const float* cond, int B, float* cross, float* vtmp) {
+  const int T = u->cross_total, dc = u->cfg.d_cond;
+  c.prof_begin(PF_K_SMALL, 0);
+  if (!c.dry) small_launch(c, launch_matvec(cond, dc, c.w(u->cross_v), nullptr, vtmp, T, B, T, dc, c.s));
+  c.prof_end();
+  if (u->cross_uniform) {
+    c.prof_begin(PF_K_SMALL, 0);
+    if (!c.dry) small_launch(c, launch_matvec(vtmp, T, c.w(u->cross_o), c.w(u->cross_b), cross, T, B, T, u->cross_c, c.s, u->cross_c, u->cross_c));
+    c.prof_end();
+    return;
+  }
+  auto each_tb = [&](const Layer& L) {
+    if (L.kind != 2) return;
+    for (const Layer::TB& tb : L.tbs) {
+      c.prof_begin(PF_K_SMALL, 0);
+      if (!c.dry) small_launch(c, launch_matvec(vtmp + tb.cross_off, T, c.w(tb.o2raw), c.w(tb.o2b), cross + tb.cross_off, T, B, L.cin, L.cin, c.s));
+      c.prof_end();
+    }
+  };
+  for (auto& b : u->in_blocks) for (auto& L : b.layers) each_tb(L);
+  for (auto& L : u->mid.layers) each_tb(L);
+  for (auto& b : u->out_blocks) for (auto& L : b.layers) each_tb(L);
+}
+
 static int run(pf_unet* u, Ctx& c, const float* x, const int64_t* t, const float* cond, float* eps) {
   const pf_unet_cfg& cfg = u->cfg;
   const int B = c.B;
   int H = cfg.img_h, W_ = cfg.img_w;
   // time embedding and every ResBlock's additive time bias
+  // (the workspace layout does not depend on what the caller prepared: the small buffers are carved either way)
   float* tsilu = c.palloc((size_t)B * u->d_t);
-  float* tb_all = c.palloc((size_t)B * u->sum_emb);
-  c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_time_embed(t, c.w(u->te_w0), c.w(u->te_b0), c.w(u->te_w2), c.w(u->te_b2), tsilu, B, cfg.channels, u->d_t, c.s)); c.prof_end();
-  c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_matvec(tsilu, u->d_t, c.w(u->emb_w), c.w(u->emb_b), tb_all, u->sum_emb, B, u->sum_emb, u->d_t, c.s)); c.prof_end();
-  float* cross_all = nullptr;  // [B][cross_total]: to_out(to_v(c)) + bias of every transformer block
+  const float* tb_all = c.palloc((size_t)B * u->sum_emb);
+  if (c.has_time) {   // hoisted: row t[b] of the caller's table (pf_unet_prepare_time) instead of two launches per forward
+    tb_all = c.prep_time; c.t_rows = t;
+  } else {
+    float* tb = const_cast<float*>(tb_all);
+    c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_time_embed(t, c.w(u->te_w0), c.w(u->te_b0), c.w(u->te_w2), c.w(u->te_b2), tsilu, B, cfg.channels, u->d_t, c.s)); c.prof_end();
+    c.prof_begin(PF_K_SMALL, 0); if (!c.dry) small_launch(c, launch_matvec(tsilu, u->d_t, c.w(u->emb_w), c.w(u->emb_b), tb, u->sum_emb, B, u->sum_emb, u->d_t, c.s)); c.prof_end();
+  }
+  const float* cross_all = nullptr;  // [B][cross_total]: to_out(to_v(c)) + bias of every transformer block
   if (c.n_cond == 1 && u->cross_total > 0) {
     const int T = u->cross_total;
-    cross_all = c.palloc((size_t)B * T);
+    float* cross_ws = c.palloc((size_t)B * T);
     float* vtmp = c.palloc((size_t)B * T);
-    c.prof_begin(PF_K_SMALL, 0);
-    if (!c.dry) small_launch(c, launch_matvec(cond, cfg.d_cond, c.w(u->cross_v), nullptr, vtmp, T, B, T, cfg.d_cond, c.s));
-    c.prof_end();
-    if (u->cross_uniform) {
-      c.prof_begin(PF_K_SMALL, 0);
-      if (!c.dry) small_launch(c, launch_matvec(vtmp, T, c.w(u->cross_o), c.w(u->cross_b), cross_all, T, B, T, u->cross_c, c.s, u->cross_c, u->cross_c));
-      c.prof_end();
-    } else {
-      auto each_tb = [&](const Layer& L) {
-        if (L.kind != 2) return;
-        for (const Layer::TB& tb : L.tbs) {
-          c.prof_begin(PF_K_SMALL, 0);
-          if (!c.dry) small_launch(c, launch_matvec(vtmp + tb.cross_off, T, c.w(tb.o2raw), c.w(tb.o2b), cross_all + tb.cross_off, T, B, L.cin, L.cin, c.s));
-          c.prof_end();
-        }
-      };
-      for (auto& b : u->in_blocks) for (auto& L : b.layers) each_tb(L);
-      for (auto& L : u->mid.layers) each_tb(L);
-      for (auto& b : u->out_blocks) for (auto& L : b.layers) each_tb(L);
-    }
+    cross_all = cross_ws;
+    if (c.has_cross) cross_all = c.prep_cross;   // hoisted (pf_unet_prepare_cond)
+    else cross_bias_launches(u, c, cond, B, cross_ws, vtmp);
   }
 
   std::vector<Tn> skips;
@@ -789,9 +801,9 @@ static int run(pf_unet* u, Ctx& c, const float* x, const int64_t* t, const float
   return c.rc;
 }
 
-static void plan_sizes(pf_unet* u, int batch, int n_cond, size_t* persist, size_t* temp, int* launches) {
+static void plan_sizes(pf_unet* u, int batch, int n_cond, size_t* persist, size_t* temp, int* launches, bool has_time = false, bool has_cross = false) {
   Ctx c{};
-  c.u = u; c.dry = true; c.B = batch; c.n_cond = n_cond; c.rc = PF_OK;
+  c.u = u; c.dry = true; c.B = batch; c.n_cond = n_cond; c.rc = PF_OK; c.has_time = has_time; c.has_cross = has_cross;
   run(u, c, nullptr, nullptr, nullptr, nullptr);
   *persist = align_up(c.persist_max, 4096);
   *temp = align_up(c.temp_max, 4096);
@@ -885,7 +897,14 @@ int pf_unet_n_launches(const pf_unet* u, int batch, int n_cond) {
 
 int pf_unet_forward(pf_unet* u, const float* x, const int64_t* t, const float* cond, int batch, int n_cond, float* eps,
                     void* workspace, size_t workspace_bytes, void* stream) {
+  return pf_unet_forward_prepared(u, x, t, cond, batch, n_cond, nullptr, eps, workspace, workspace_bytes, stream);
+}
+
+int pf_unet_forward_prepared(pf_unet* u, const float* x, const int64_t* t, const float* cond, int batch, int n_cond, const pf_unet_prepared* prep,
+                             float* eps, void* workspace, size_t workspace_bytes, void* stream) {
   PF_REQUIRE(u && x && t && cond && eps && workspace, "pf_unet_forward: null argument");
+  PF_REQUIRE(!prep || !prep->time_table || prep->n_time_rows > 0, "pf_unet_forward: time table without rows");
+  PF_REQUIRE(!prep || !prep->cross_bias || n_cond == 1, "pf_unet_forward: the collapsed cross-attention bias exists only for n_cond == 1");
   PF_REQUIRE(batch > 0 && n_cond > 0, "pf_unet_forward: batch and n_cond must be positive");
   if (!u->wdev) return set_error(PF_ESTATE, "pf_unet_forward: weights not bound (call pf_unet_bind_weights)");
   PF_REQUIRE(n_cond == 1 || u->cfg.d_cond % 32 == 0, "pf_unet_forward: n_cond > 1 needs d_cond %% 32 == 0");
@@ -896,9 +915,55 @@ int pf_unet_forward(pf_unet* u, const float* x, const int64_t* t, const float* c
   Ctx c{};
   c.u = u; c.s = (hipStream_t)stream; c.dry = false; c.base = (char*)workspace; c.temp_base = p;
   c.B = batch; c.n_cond = n_cond; c.W = u->wdev; c.rc = PF_OK;
+  if (prep && prep->time_table) { c.has_time = true; c.prep_time = prep->time_table; c.prep_time_rows = prep->n_time_rows; }
+  if (prep && prep->cross_bias && u->cross_total > 0) { c.has_cross = true; c.prep_cross = prep->cross_bias; }
   if (u->profiling) { u->n_prof = 0; u->pkind.clear(); u->pflops.clear(); }
   return run(u, c, x, t, cond, eps);
 }
+
+int pf_unet_time_bias_width(const pf_unet* u) { return u ? u->sum_emb : 0; }
+int pf_unet_cross_bias_width(const pf_unet* u) { return u ? u->cross_total : 0; }
+
+int pf_unet_prepare_time(pf_unet* u, int n_rows, float* table, void* scratch, size_t scratch_bytes, void* stream) {
+  PF_REQUIRE(u && table && scratch && n_rows > 0, "pf_unet_prepare_time: bad arguments");
+  if (!u->wdev) return set_error(PF_ESTATE, "pf_unet_prepare_time: weights not bound (call pf_unet_bind_weights)");
+  PF_REQUIRE(scratch_bytes >= (size_t)n_rows * u->d_t * sizeof(float), "pf_unet_prepare_time: scratch too small (%zu < %zu)", scratch_bytes,
+             (size_t)n_rows * u->d_t * sizeof(float));
+  const float* W = u->wdev;
+  float* tsilu = static_cast<float*>(scratch);
+  // the same two launches forward issues per call (row r <- time-step value r): bit-identical to the unprepared path
+  int rc = launch_time_embed(nullptr, W + u->te_w0, W + u->te_b0, W + u->te_w2, W + u->te_b2, tsilu, n_rows, u->cfg.channels, u->d_t, (hipStream_t)stream);
+  if (rc != PF_OK) return rc;
+  return launch_matvec(tsilu, u->d_t, W + u->emb_w, W + u->emb_b, table, u->sum_emb, n_rows, u->sum_emb, u->d_t, (hipStream_t)stream);
+}
+
+int pf_unet_prepare_cond(pf_unet* u, const float* cond, int batch, float* cross, void* scratch, size_t scratch_bytes, void* stream) {
+  PF_REQUIRE(u && cond && cross && scratch && batch > 0, "pf_unet_prepare_cond: bad arguments");
+  if (!u->wdev) return set_error(PF_ESTATE, "pf_unet_prepare_cond: weights not bound (call pf_unet_bind_weights)");
+  PF_REQUIRE(u->cross_total > 0, "pf_unet_prepare_cond: this UNet has no transformer block");
+  PF_REQUIRE(scratch_bytes >= (size_t)batch * u->cross_total * sizeof(float), "pf_unet_prepare_cond: scratch too small");
+  Ctx c{};
+  c.u = u; c.s = (hipStream_t)stream; c.dry = false; c.B = batch; c.n_cond = 1; c.W = u->wdev; c.rc = PF_OK;
+  const bool prof = u->profiling;
+  u->profiling = false;
+  cross_bias_launches(u, c, cond, batch, cross, static_cast<float*>(scratch));
+  u->profiling = prof;
+  return c.rc;
+}
+
+int pf_unet_n_launches_prepared(const pf_unet* u, int batch, int n_cond, int has_time, int has_cross) {
+  if (!u || batch <= 0 || n_cond <= 0) return 0;
+  size_t p, t; int n = 0;
+  plan_sizes(const_cast<pf_unet*>(u), batch, n_cond, &p, &t, &n, has_time != 0, has_cross != 0 && n_cond == 1);
+  return n;
+}
+
+int pf_unet_set_option(pf_unet* u, int option, int value) {
+  PF_REQUIRE(u && option >= 0 && option < PF_OPT_COUNT && value >= PF_OPT_AUTO && value <= PF_OPT_ON, "pf_unet_set_option: bad arguments");
+  u->opt[option] = value;
+  return PF_OK;
+}
+int pf_unet_get_option(const pf_unet* u, int option) { return (u && option >= 0 && option < PF_OPT_COUNT) ? u->opt[option] : -2; }
 
 int pf_unet_set_precision(pf_unet* u, int precision) {
   PF_REQUIRE(u && (precision == PF_PREC_F32 || precision == PF_PREC_BF16X3), "pf_unet_set_precision: bad arguments");
@@ -966,12 +1031,6 @@ int pf_mlp_geglu_proj_fused(const float* x, int batch, int l, const float* ln_ga
   return launch_mlp_fused(x, batch, l, ln_gamma, ln_beta, ln_eps, w1_bf16x3, b1, w2_bf16x3, b2, out, nullptr, (hipStream_t)stream, w3_bf16x3, b3,
                           res3, stats3);
 }
-int pf_transformer_tail_fused(const pf_tblock_tail_args* a, void* stream) {
-  if (!a || !a->attn_planes || !a->wo || !a->bo || !a->x0 || !a->x1) return set_error(PF_EINVAL, "pf_transformer_tail_fused: null argument");
-  MlpHead h{a->attn_planes, a->wo, a->bo, a->cross_bias, a->ld_cross_bias, a->x0};
-  return launch_mlp_fused(a->x1, a->batch, a->l, a->ln_gamma, a->ln_beta, a->ln_eps, a->w1, a->b1, a->w2, a->b2, a->out, a->out_planes,
-                          (hipStream_t)stream, a->w3, a->b3, a->res3, a->stats3, &h);
-}
 int pf_ln_planes(const float* x, int rows, int c, float eps, const float* gamma, const float* beta, void* planes, void* stream) {
   return launch_ln_planes(x, rows, c, eps, gamma, beta, planes, (hipStream_t)stream);
 }
@@ -989,8 +1048,8 @@ int pf_conv2d(const pf_conv_args* a, void* stream) {
   PF_REQUIRE(a, "pf_conv2d: null argument");
   return launch_conv(*a, (hipStream_t)stream);
 }
-int pf_attention_bf16x3(const void* qkv_planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, void* stream) {
-  return launch_attention_bf3(qkv_planes, o, ldo, o_planes, batch, n_heads, l, (hipStream_t)stream);
+int pf_attention_bf16x3(const void* qkv_planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, int form, void* stream) {
+  return launch_attention_bf3(qkv_planes, o, ldo, o_planes, batch, n_heads, l, form, (hipStream_t)stream);
 }
 int pf_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int batch,
                  int n_heads, int d_head, int lq, int lk, void* stream) {
@@ -1013,6 +1072,28 @@ int pf_ddim_step(const float* x, const float* eps, const float* noise, const flo
 int pf_randn(float* out, size_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, void* stream) {
   return launch_randn(out, n, seed, stream_id, elem_offset, (hipStream_t)stream);
 }
+int pf_ddpm_step_rng(const float* x, const float* eps, const float* orig, const float* mask, const pf_ddpm_coef* c, uint64_t seed,
+                     uint64_t draw_q, uint64_t draw_p, uint64_t elem_offset, float* x_out, size_t n, void* stream) {
+  PF_REQUIRE(c, "pf_ddpm_step_rng: null coefficients");
+  return launch_ddpm_step_rng(x, eps, orig, mask, c, nullptr, nullptr, seed, draw_q, draw_p, elem_offset, x_out, n, (hipStream_t)stream);
+}
+int pf_ddim_step_rng(const float* x, const float* eps, const float* orig, const float* orig_noise, const float* mask, const pf_ddim_coef* c,
+                     uint64_t seed, uint64_t draw, uint64_t elem_offset, float* x_out, size_t n, void* stream) {
+  PF_REQUIRE(c, "pf_ddim_step_rng: null coefficients");
+  return launch_ddim_step_rng(x, eps, orig, orig_noise, mask, c, nullptr, nullptr, seed, draw, elem_offset, x_out, n, (hipStream_t)stream);
+}
+int pf_ddpm_step_rng_dev(const float* x, const float* eps, const float* orig, const float* mask, const pf_ddpm_coef* table,
+                         const pf_step_state* st, uint64_t seed, uint64_t elem_offset, float* x_out, size_t n, void* stream) {
+  PF_REQUIRE(table && st, "pf_ddpm_step_rng_dev: null table / state");
+  return launch_ddpm_step_rng(x, eps, orig, mask, nullptr, table, st, seed, 0, 0, elem_offset, x_out, n, (hipStream_t)stream);
+}
+int pf_ddim_step_rng_dev(const float* x, const float* eps, const float* orig, const float* orig_noise, const float* mask,
+                         const pf_ddim_coef* table, const pf_step_state* st, uint64_t seed, uint64_t elem_offset, float* x_out, size_t n,
+                         void* stream) {
+  PF_REQUIRE(table && st, "pf_ddim_step_rng_dev: null table / state");
+  return launch_ddim_step_rng(x, eps, orig, orig_noise, mask, nullptr, table, st, seed, 0, elem_offset, x_out, n, (hipStream_t)stream);
+}
+int pf_clock_probe(uint64_t* out2, void* stream) { return launch_clock_probe(reinterpret_cast<unsigned long long*>(out2), (hipStream_t)stream); }
 int pf_step_state_set(pf_step_state* st, int64_t index, uint64_t draws, void* stream) { return launch_step_state_set(st, index, draws, (hipStream_t)stream); }
 int pf_step_begin(const pf_step_state* st, const int32_t* time_steps, int64_t* t_out, int batch, void* stream) {
   return launch_step_begin(st, time_steps, t_out, batch, (hipStream_t)stream);

@@ -133,3 +133,114 @@ class DataSample:
                 i += 1
         return (torch.from_numpy(np.array(prmat2c, dtype=np.float32)), torch.from_numpy(np.array(pnotree, dtype=np.int64)),
                 torch.from_numpy(np.array(chord, dtype=np.float32)), torch.from_numpy(np.array(prmat, dtype=np.float32)))
+
+
+# ---- validation-set song files (ref:data/dataset.py:27-253, data/dataset_musicalion.py:25-208) ----------------------------------------
+# PARITY UNPINNED: the POP909 / Musicalion .npz collections are not part of the reference checkout (only the split lists under
+# data/train_split_pnt/ are) and no fixture of the reference holds one of their files; the classes below restate the reference's
+# loaders for the file layout those loaders document, and are tested on synthetic files of that layout.
+POP909_DATA_DIR = "data/POP909_4_bin_pnt_8bar"              # ref:dirs.py:8-9
+MUSICALION_DATA_DIR = "data/musicalion_solo_piano_4_bin_pnt"
+TRAIN_SPLIT_DIR = "data/train_split_pnt"                    # ref:dirs.py:5
+
+
+class DataSampleNpz(DataSample):
+    """ref:data/dataset.py:27-253 - one POP909 song: ``notes`` / ``start_table`` hold one entry per TRACK (melody, bridge, piano) and
+    ``use_track`` says which of them make up the segment (rows of the chosen tracks one after the other, in track order - the
+    reference does not re-sort them, :103-124).  A file with a single note matrix (0-d ``start_table``) is read like ``DataSample``."""
+
+    def __init__(self, song_fn: str, use_track=(0, 1, 2), data_dir: str = POP909_DATA_DIR) -> None:
+        import os
+        self.song_fn, self.use_track = song_fn, list(use_track)
+        with np.load(os.path.join(data_dir, song_fn), allow_pickle=True) as z:
+            data = {k: z[k] for k in ("notes", "start_table", "db_pos", "db_pos_filter", "chord")}
+        st = data["start_table"]
+        self.multi_track = st.ndim > 0                       # ref:dataset.py:103 `len(self.start_table.shape) > 0`
+        if self.multi_track:
+            self.notes = [np.asarray(n) for n in data["notes"]]
+            self.start_table = [dict(t) for t in st]
+        else:
+            self.notes, self.start_table = np.asarray(data["notes"]), st.item()
+        db = np.asarray(data["db_pos"])
+        self.db_pos_filter = np.asarray(data["db_pos_filter"])
+        self.db_pos = db[self.db_pos_filter]
+        if len(self.db_pos) != 0:
+            self.last_db = self.db_pos[-1]
+        self.chord = np.asarray(data["chord"]).astype(np.int32)
+
+    def note_mat_seg_at_db(self, db: int) -> np.ndarray:
+        if not self.multi_track:
+            return DataSample.note_mat_seg_at_db(self, db)
+        rows = []
+        for t in self.use_track:
+            notes, table = self.notes[t], self.start_table[t]
+            s = table[db]
+            seg = notes[s:table[db + SEG_LGTH_BIN]] if db + SEG_LGTH_BIN in table else notes[s:]
+            rows.extend(np.array(seg))
+        out = np.array(rows)
+        return out if out.size else np.zeros([0, 5], dtype=np.int64)
+
+
+class DataSampleNpz_Musicalion(DataSample):
+    """ref:data/dataset_musicalion.py:25-208 - one Musicalion song: a single note matrix, NO chord track (``chord`` comes back ``None``,
+    so only texture / piano-tree conditioned models can use it - the reference asserts ``cond_type != "chord"``, inference_sdf.py:620)."""
+
+    def __init__(self, song_fn: str, data_dir: str = MUSICALION_DATA_DIR) -> None:
+        import os
+        self.song_fn = song_fn
+        with np.load(os.path.join(data_dir, song_fn), allow_pickle=True) as z:
+            self.notes, self.start_table = np.asarray(z["notes"]), z["start_table"].item()
+            db, self.db_pos_filter = np.asarray(z["db_pos"]), np.asarray(z["db_pos_filter"])
+        self.db_pos = db[self.db_pos_filter]
+        if len(self.db_pos) != 0:
+            self.last_db = self.db_pos[-1]
+        self.chord = None
+
+    def __getitem__(self, idx: int):
+        db = int(self.db_pos[idx])
+        nmat = self._nmat(db)
+        return nmat_to_prmat2c(nmat, SEG_LGTH_BIN), nmat_to_pianotree_repr(nmat, SEG_LGTH_BIN), None, nmat_to_prmat(nmat, SEG_LGTH_BIN)
+
+    def get_whole_song_data(self):
+        prmat2c, pnotree, prmat = [], [], []
+        idx = i = 0
+        while i < len(self):
+            p2, pt, _, pm = self[i]
+            prmat2c.append(p2); pnotree.append(pt); prmat.append(pm)
+            idx += SEG_LGTH_BIN
+            while i < len(self) and self.db_pos[i] < idx:
+                i += 1
+        return (torch.from_numpy(np.array(prmat2c, dtype=np.float32)), torch.from_numpy(np.array(pnotree, dtype=np.int64)), None,
+                torch.from_numpy(np.array(prmat, dtype=np.float32)))
+
+
+def load_split(path: str):
+    """ref:inference_sdf.py:96-98 - the (train files, validation files) pair of a split pickle.  The reference calls ``pickle.load``; a
+    split is two lists of file names, so this loader admits exactly that (tuples / lists of str) and refuses every global."""
+    import pickle
+
+    class _NoGlobals(pickle.Unpickler):
+        def find_class(self, module, name):
+            raise pickle.UnpicklingError(f"split pickle refers to {module}.{name}: only lists of file names are expected")
+
+    with open(path, "rb") as f:
+        split = _NoGlobals(f).load()
+    if not (isinstance(split, (tuple, list)) and len(split) == 2 and all(isinstance(s, (list, tuple)) and all(isinstance(n, str) for n in s) for s in split)):
+        raise ValueError(f"{path}: expected a (train, validation) pair of file-name lists")
+    return list(split[0]), list(split[1])
+
+
+def choose_song_from_val_dl(dataset: str, index=None, use_track=(0, 1, 2), data_dir=None, split_dir: str = TRAIN_SPLIT_DIR, ask=input):
+    """ref:inference_sdf.py:95-118 (``choose_song_from_val_dl`` / ``..._musicalion``): a song of the VALIDATION half of the split, by
+    ``index`` or - like the reference - by asking on the terminal.  Returns (sample object, file name)."""
+    import os
+    if dataset not in ("pop909", "musicalion"):
+        raise NotImplementedError(dataset)                       # ref:inference_sdf.py:590, 623
+    val = load_split(os.path.join(split_dir, f"{dataset}.pickle"))[1]
+    if index is None:
+        print(val)
+        index = int(ask(f"choose one from {dataset}:"))
+    song_fn = val[int(index)]
+    if dataset == "pop909":
+        return DataSampleNpz(song_fn, use_track, data_dir or POP909_DATA_DIR), song_fn
+    return DataSampleNpz_Musicalion(song_fn, data_dir or MUSICALION_DATA_DIR), song_fn

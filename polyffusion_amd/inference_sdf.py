@@ -314,12 +314,17 @@ def make_parser() -> ArgumentParser:
     p.add_argument("--uncond_scale", type=float, default=1.0, help="unconditional scale for classifier-free guidance")
     p.add_argument("--seed", type=int, help="use a specific seed for inference")
     p.add_argument("--autoreg", action="store_true", help="autoregressively inpaint the music segments")
-    p.add_argument("--from_dataset", default=None, help="(not rebuilt) choose condition from a dataset")
+    p.add_argument("--from_dataset", default=None, help="choose condition from a dataset {pop909, musicalion} (validation half of its split)")
+    p.add_argument("--dataset_dir", help="extension: directory of the dataset's song .npz files (default: the reference's dirs.py paths)")
+    p.add_argument("--split_dir", default=datasample.TRAIN_SPLIT_DIR, help="extension: directory of the <dataset>.pickle split files")
+    p.add_argument("--song_index", type=int, help="extension: index into the validation list (the reference asks on the terminal)")
+    p.add_argument("--song_index2", type=int, help="extension: the same for the texture song of chord+txt models")
+    p.add_argument("--inpaint_song_index", type=int, help="extension: the same for --inpaint_from_dataset")
     p.add_argument("--from_midi", help="choose condition from a midi file")
     p.add_argument("--from_midi2", help="choose condition from the 2nd midi file. Used for chord+txt conditioning")
     p.add_argument("--inpaint_from_midi", help="inpaint a midi file")
-    p.add_argument("--inpaint_from_dataset", default=None, help="(not rebuilt)")
-    p.add_argument("--inpaint_pop909_use_track", help="(not rebuilt)")
+    p.add_argument("--inpaint_from_dataset", default=None, help="inpaint a song from a dataset {pop909, musicalion}")
+    p.add_argument("--inpaint_pop909_use_track", help="which tracks to use as base song for inpainting, default: 0,1,2")
     p.add_argument("--inpaint_type", help="inpaint a song, type: {remaining, below, above, bars}")
     p.add_argument("--ddim", action="store_true", help="whether to use DDIM sampler")
     p.add_argument("--ddim_discretize", default="uniform", help="{uniform(default), quad}")
@@ -454,10 +459,6 @@ def generate_songs(model, params, args, cond, cond_mid, orig, mask, seed: int, r
 def main(argv=None):
     from . import dist as pfdist
     args = make_parser().parse_args(argv)
-    for flag in ("from_dataset", "inpaint_from_dataset", "inpaint_pop909_use_track"):
-        if getattr(args, flag) is not None:
-            raise SystemExit(f"--{flag}: the POP909 / Musicalion validation sets are not part of this build; use --from_midi, "
-                             "--from_song_npz (one song in the same dictionary format), --cond_npz or --synthetic")
     if not torch.cuda.is_available():
         raise SystemExit("inference_sdf needs an AMD GPU (no CPU fallback on this path)")
     rank, world, _ = pfdist.init_from_env()
@@ -493,25 +494,58 @@ def main(argv=None):
     model = load_model(params, args, rank, world)
 
     length = args.length
-    chd = prmat = prmat2c_inp = pnotree = None
+    # prmat2c_cond: the CONDITION song's image (what concat_blurry blurs, ref:inference_sdf.py:797-803 uses `prmat2c`);
+    # prmat2c_inp: the song to inpaint (`prmat2c_inp`, :565-591).  Two variables, as in the reference.
+    chd = prmat = prmat2c_cond = prmat2c_inp = pnotree = None
+    cond_is_dummy = False
     def song_from_midi(path, tag):
-        # ref:inference_sdf.py:606-612 - quantise the file, extract its chords (written next to the outputs, as the reference's exp/*.out)
+        # ref:inference_sdf.py:606-612 - quantise the file, extract its chords (written next to the outputs, as the reference's exp/*.out:
+        # by rank 0 only - every rank extracts the same labels and keeps them in memory)
         from . import midi_to_data
-        data = midi_to_data.get_data_for_single_midi(path, os.path.join(args.output_dir, f"chords_extracted{tag}.out"))
+        if rank == 0:
+            os.makedirs(args.output_dir, exist_ok=True)
+        data = midi_to_data.get_data_for_single_midi(path, os.path.join(args.output_dir, f"chords_extracted{tag}.out") if rank == 0 else None)
         if data is None:
             raise SystemExit(f"{path}: a barline does not fall on the 16th-note grid (get_downbeat_pos_and_filter)")
         return datasample.DataSample(data).get_whole_song_data()
+
+    def song_from_dataset(name, index, use_track=(0, 1, 2)):
+        # ref:inference_sdf.py:95-118 - a song of the validation half of the dataset's split (parity unpinned: the datasets are not shipped)
+        try:
+            sample, fn = datasample.choose_song_from_val_dl(name, index, use_track, args.dataset_dir, args.split_dir)
+        except FileNotFoundError as e:
+            raise SystemExit(f"--from_dataset {name}: {e} (give --dataset_dir / --split_dir)")
+        return sample.get_whole_song_data(), fn
 
     inp_from_midi = None
     if args.inpaint_type is not None and args.inpaint_from_midi is not None:    # :569-575
         inp_from_midi = song_from_midi(args.inpaint_from_midi, "_inpaint")[0].to(_dev())
         say(f"Inpainting midi file: {args.inpaint_from_midi}")
-    if args.from_song_npz is not None:
+    elif args.inpaint_type is not None and args.inpaint_from_dataset is not None:   # :576-590
+        tracks = [int(v) for v in args.inpaint_pop909_use_track.split(",")] if args.inpaint_pop909_use_track else [0, 1, 2]
+        (p2c, _, _, _), fn = song_from_dataset(args.inpaint_from_dataset, args.inpaint_song_index, tracks)
+        inp_from_midi = p2c.to(_dev())
+        say(f"Inpainting midi file: {fn}")
+    if args.from_dataset is not None and args.uncond_scale != 0.0:                # :613-624
+        if args.from_dataset == "musicalion" and params.cond_type == "chord":
+            raise SystemExit("--from_dataset musicalion has no chord track (ref:inference_sdf.py:620 asserts cond_type != 'chord')")
+        (p2c, pnotree, chd, prmat), fn = song_from_dataset(args.from_dataset, args.song_index)
+        chd = None if chd is None else chd.to(_dev())
+        prmat, prmat2c_cond, pnotree = prmat.to(_dev()), p2c.to(_dev()), pnotree.to(_dev())
+        say(f"using the {params.cond_type.split('+')[0]} of midi file: {fn}")
+        if params.cond_type == "chord+txt" and args.from_midi2 is None:           # texture from a second song of the set (:636-641)
+            (_, _, _, prmat2), fn2 = song_from_dataset(args.from_dataset, args.song_index2)
+            prmat = prmat2.to(_dev())
+            say(f"using the txt of midi file: {fn2}")
+        elif params.cond_type == "chord+txt":
+            prmat = song_from_midi(args.from_midi2, "")[3].to(_dev())
+            say(f"using the txt of midi file: {args.from_midi2}")
+    elif args.from_song_npz is not None:
         p2c, pnotree, chd, prmat = datasample.DataSample.from_npz(args.from_song_npz).get_whole_song_data()
-        chd, prmat, prmat2c_inp, pnotree = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev()), pnotree.to(_dev())
+        chd, prmat, prmat2c_cond, pnotree = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev()), pnotree.to(_dev())
     elif args.from_midi is not None and args.uncond_scale != 0.0:
         p2c, pnotree, chd, prmat = song_from_midi(args.from_midi, "")
-        chd, prmat, prmat2c_inp, pnotree = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev()), pnotree.to(_dev())
+        chd, prmat, prmat2c_cond, pnotree = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev()), pnotree.to(_dev())
         say(f"using the {params.cond_type.split('+')[0]} of midi file: {args.from_midi}")
         if params.cond_type == "chord+txt" and args.from_midi2 is not None:      # texture from a second file (:630-635)
             prmat = song_from_midi(args.from_midi2, "")[3].to(_dev())
@@ -521,12 +555,13 @@ def main(argv=None):
             length = inp_from_midi.shape[0]            # :596-597
         if length <= 0:
             raise SystemExit("--length is required for unconditional generation")
-        _, pnotree, chd, prmat = dummy_cond_input(length, params)
+        prmat2c_cond, pnotree, chd, prmat = dummy_cond_input(length, params)   # zeros: what an unconditional concat_blurry model blurs
+        cond_is_dummy = True
     elif args.cond_npz is not None:
         z = np.load(args.cond_npz)
         chd = torch.from_numpy(z["chord"]).float().to(_dev()) if "chord" in z else None
         prmat = torch.from_numpy(z["prmat"]).float().to(_dev()) if "prmat" in z else None
-        prmat2c_inp = torch.from_numpy(z["prmat2c"]).float().to(_dev()) if "prmat2c" in z else None
+        prmat2c_cond = torch.from_numpy(z["prmat2c"]).float().to(_dev()) if "prmat2c" in z else None
         pnotree = torch.from_numpy(z["pnotree"]).long().to(_dev()) if "pnotree" in z else None
     elif args.synthetic:
         n = length if length > 0 else 1
@@ -546,8 +581,8 @@ def main(argv=None):
         cond = cond[:length]
         cond_mid = cond_mid[:length] if cond_mid is not None else None
     orig = mask = None
-    if inp_from_midi is not None:
-        prmat2c_inp = inp_from_midi
+    # the image to inpaint: --inpaint_from_midi, else (an extension of the reference, whose dataset branches are absent here) the condition song
+    prmat2c_inp = inp_from_midi if inp_from_midi is not None else (None if cond_is_dummy else prmat2c_cond)
     if args.inpaint_type is not None:
         if prmat2c_inp is None:
             raise SystemExit("--inpaint_type needs the image to inpaint: --inpaint_from_midi, prmat2c in --cond_npz, or a --from_midi / --from_song_npz song")
@@ -560,9 +595,10 @@ def main(argv=None):
     cond_concat = None
     if params.get("concat_blurry", False):
         # inference_sdf.py:797-803 - the denoiser of this variant takes cat([x, blurry image], 1)
-        if prmat2c_inp is None:
-            raise SystemExit("params.concat_blurry needs the image to blur: prmat2c in --cond_npz (or a --from_song_npz song)")
-        cond_concat = get_blurry_image(prmat2c_inp[:cond.shape[0]], params.get("concat_ratio", 1 / 8))
+        if prmat2c_cond is None:
+            raise SystemExit("params.concat_blurry needs the condition song's image to blur: --from_midi, --from_song_npz, prmat2c in --cond_npz, "
+                             "or --uncond_scale 0 --length N (zeros)")
+        cond_concat = get_blurry_image(prmat2c_cond[:cond.shape[0]], params.get("concat_ratio", 1 / 8))
         n = min(cond.shape[0], cond_concat.shape[0])
         cond, cond_concat = cond[:n], cond_concat[:n]
         cond_mid = None if cond_mid is None else cond_mid[:n]

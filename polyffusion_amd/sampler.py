@@ -12,9 +12,16 @@ them unchanged.  Differences, all host-side plumbing:
     per step (``pf_ddpm_step`` / ``pf_ddim_step``) instead of ~20 elementwise launches and five
     device->host syncs per step;
   - noise comes from ``noise_fn(shape)`` when given (parity tests inject the reference's noise
-    tape) and otherwise from the counter-based on-device generator ``pf_randn`` keyed by
-    (seed, draw counter, global sample index), so a batch sharded over N GPUs draws the same
-    noise per sample as the unsharded batch.
+    tape) and otherwise from the counter-based on-device generator keyed by (seed, draw counter,
+    global sample index), so a batch sharded over N GPUs draws the same noise per sample as the
+    unsharded batch.  Inside the loops the draws happen IN the update kernel
+    (``pf_ddpm_step_rng`` / ``pf_ddim_step_rng``: bit-identical to ``pf_randn`` + step, two
+    launches and the noise tensors' HBM round trips less per step);
+  - what the eps model computes from ``t`` and ``cond`` alone - the time MLP with every
+    ResBlock's ``emb_layers`` and, for one context token, the whole cross-attention - is hoisted
+    out of the loops: ``prepare()`` builds it once per ``paint()`` / ``sample()`` call and every
+    step's forward receives it (``UNetModel.forward(time_table=, cross_bias=)``).  ``p_sample`` /
+    ``get_eps`` called on their own keep working unprepared.
 """
 from __future__ import annotations
 
@@ -42,7 +49,7 @@ class DiffusionSampler:
         self.sample_offset = int(sample_offset)  # global index of this rank's first sample (multi-GPU sharding)
         self._draws = 0
         self._lib = _lib.load()
-        self._tbuf = None
+        self._trows = None
         # graph=True: paint() captures ONE reverse step as a hipGraph and replays it.  What varies per step
         # (table row, time-step value, noise draw counter) lives in a device-resident pf_step_state, the coefficient table is on
         # the device, x is updated in place: a replay issues no host-side launches (about 220 per step in eager mode), which is
@@ -75,17 +82,19 @@ class DiffusionSampler:
         return (0 if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), 0 if blob is None else blob.data_ptr(),
                 getattr(m, "precision", None))
 
-    def _graph_for(self, key, inputs, make_body, reset):
+    def _graph_for(self, key, inputs, make_body, reset, uncond_scale=1.0):
         """The captured step for `key`, with `inputs` (name -> tensor or None) copied into its static buffers.  A cached entry is
         dropped when the UNet's workspace / weights / mode changed since its capture.  `make_body(bufs)` returns the step closure
         over the static buffers, `reset()` re-arms the device step state (called after every buffer refresh).  Returns the entry
-        {"g": graph, "bufs": {...}}."""
+        {"g": graph, "bufs": {...}}.  bufs["_prep"] holds the hoisted prefix (prepare()) in static buffers of its own: it is
+        recomputed IN PLACE from the refreshed cond buffers on every call, so the captured forward always reads current values."""
         ent = self._graphs.get(key)
         if ent is not None and ent["token"] != self._graph_token():
             del self._graphs[key]
             ent = None
         if ent is None:
             bufs = {k: (None if v is None else v.clone()) for k, v in inputs.items()}
+            bufs["_prep"] = self.prepare(bufs["cond"], uncond_scale=uncond_scale, uncond_cond=bufs.get("uncond_cond"))
 
             def restore():
                 bufs["x"].copy_(inputs["x"])
@@ -101,6 +110,7 @@ class DiffusionSampler:
             for k, v in inputs.items():
                 if v is not None:
                     ent["bufs"][k].copy_(v)
+            self.prepare(ent["bufs"]["cond"], uncond_scale=uncond_scale, uncond_cond=ent["bufs"].get("uncond_cond"), out=ent["bufs"]["_prep"])
             reset()
         return ent
 
@@ -134,27 +144,64 @@ class DiffusionSampler:
         self._draws += 1
         return out
 
+    # ---- the step-invariant prefix of the eps model, hoisted out of the loops ------------------------------
+    def prepare(self, cond: torch.Tensor, *, uncond_scale: float = 1.0, uncond_cond: Optional[torch.Tensor] = None,
+                out: Optional[dict] = None) -> dict:
+        """What ``get_eps(x, t, cond, uncond_scale=, uncond_cond=)`` computes WITHOUT looking at x, for every t of the schedule:
+        ``time_table`` [n_steps, W] (time MLP + all ``emb_layers`` per time-step value, ``unet.py:181-182, 286-289``) and ``cross`` -
+        the collapsed one-token cross-attention biases (``unet_attention.py:186-212``) of exactly the context batch ``get_eps`` feeds
+        the model: ``cond``, ``uncond_cond`` or ``cat([uncond_cond, cond])`` by the reference's exact-float branches
+        (``sampler/__init__.py:63-74``).  ``None`` entries (several context tokens) are computed inside every forward as before.
+        Called explicitly by the loops of this class; pass the result as ``prep=`` with the SAME cond / guidance arguments.
+        ``out``: a previous result whose buffers are overwritten in place (captured-graph replay)."""
+        m = self.model.eps_model
+        if uncond_cond is None or uncond_scale == 1.0:
+            ctx = cond
+        elif uncond_scale == 0.0:
+            ctx = uncond_cond
+        else:
+            ctx = torch.cat([uncond_cond, cond])
+        o = out or {}
+        # one row more than the schedule has steps: the DDIM tau table is shifted by +1 (sampler_ddim.py:63-73)
+        return {"time_table": m.prepare_time(self.model.n_steps + 1, out=o.get("time_table")),
+                "cross": m.prepare_cond(ctx, out=o.get("cross"))}
+
+    @staticmethod
+    def _prep_kw(prep):
+        return {} if prep is None else {"time_table": prep["time_table"], "cross_bias": prep["cross"]}
+
     # ---- eps with classifier-free guidance ----------------------------------------------------------
     def get_eps(self, x: torch.Tensor, t: torch.Tensor, c: torch.Tensor, *, uncond_scale: float,
-                uncond_cond: Optional[torch.Tensor]):
+                uncond_cond: Optional[torch.Tensor], prep: Optional[dict] = None):
+        kw = self._prep_kw(prep)
         if uncond_cond is None or uncond_scale == 1.0:
-            return self.model(x, t, c)
+            return self.model(x, t, c, **kw)
         elif uncond_scale == 0.0:
-            return self.model(x, t, uncond_cond)
+            return self.model(x, t, uncond_cond, **kw)
         # re-concatenated on every call like the reference (sampler/__init__.py:69-74): [2B,n_cond,d_cond] is a few KB, and a
         # cache keyed on addresses could serve a stale tensor after an in-place update or an allocator address reuse
-        eps2 = self.model(torch.cat([x, x]), torch.cat([t, t]), torch.cat([uncond_cond, c]))
+        eps2 = self.model(torch.cat([x, x]), torch.cat([t, t]), torch.cat([uncond_cond, c]), **kw)
         e_t = torch.empty_like(eps2[: x.shape[0]])   # eps has out_channels; x may carry extra cond_concat channels
         _lib.check(self._lib.pf_cfg_combine(eps2.data_ptr(), float(uncond_scale), e_t.data_ptr(), e_t.numel(),
                                             _lib.current_stream()), "pf_cfg_combine")
         return e_t
 
-    def _eps(self, x, c, step, uncond_scale, uncond_cond, cond_concat):
-        if self._tbuf is None or self._tbuf.shape[0] != x.shape[0] or self._tbuf.device != x.device:
-            self._tbuf = torch.empty(x.shape[0], dtype=torch.long, device=x.device)
-        t = self._tbuf.fill_(int(step))  # stream-ordered: the previous step's UNet has consumed the old value
+    def _t_of(self, step: int, batch: int, device) -> torch.Tensor:
+        """[batch] int64 on the device, all == step: a row of a constant [n_steps, batch] table (no fill launch per step)."""
+        tr = self._trows
+        if tr is None or tr.shape[1] != batch or tr.device != device:
+            tr = self._trows = torch.arange(self.model.n_steps + 1, dtype=torch.long, device=device).unsqueeze(1).repeat(1, batch).contiguous()
+        return tr[int(step)]
+
+    def _eps(self, x, c, step, uncond_scale, uncond_cond, cond_concat, prep=None):
+        t = self._t_of(step, x.shape[0], x.device)
         xin = x if cond_concat is None else torch.cat([x, cond_concat], dim=1)
-        return self.get_eps(xin, t, c, uncond_scale=uncond_scale, uncond_cond=uncond_cond)
+        return self.get_eps(xin, t, c, uncond_scale=uncond_scale, uncond_cond=uncond_cond, prep=prep)
+
+    def _rng_ok(self, x) -> bool:
+        """The in-kernel noise path: on-device generator, whole Philox groups per tensor and per shard."""
+        per_sample = x.numel() // x.shape[0]
+        return self.noise_fn is None and x.numel() % 4 == 0 and (self.sample_offset * per_sample) % 4 == 0
 
 
 class SDFSampler(DiffusionSampler):
@@ -191,27 +238,34 @@ class SDFSampler(DiffusionSampler):
         ndraw = 2 if orig is not None else 1
         inputs = dict(x=x, cond=cond, orig=orig, mask=mask, uncond_cond=uncond_cond, cond_concat=cond_concat)
 
+        rng = self._rng_ok(x)
+
         def make_body(bf):
-            xb, tb, npz = bf["x"], torch.empty(B, dtype=torch.long, device=dev), torch.empty_like(bf["x"])
-            nq = torch.empty_like(xb) if bf["orig"] is not None else None
+            xb, tb = bf["x"], torch.empty(B, dtype=torch.long, device=dev)
+            npz = None if rng else torch.empty_like(xb)
+            nq = torch.empty_like(xb) if (bf["orig"] is not None and not rng) else None
             bf["_keep"] = (tb, npz, nq)
 
             def body():
                 stream = _lib.current_stream()
                 _lib.check(lib.pf_step_begin(st.data_ptr(), None, tb.data_ptr(), B, stream), "pf_step_begin")
-                if nq is not None:   # draw order of the reference: known-region noise first, then the p_sample noise
-                    _lib.check(lib.pf_randn_dev(nq.data_ptr(), n, self.seed, st.data_ptr(), 0, off, stream), "pf_randn_dev")
                 xin = xb if bf["cond_concat"] is None else torch.cat([xb, bf["cond_concat"]], dim=1)
-                e_t = self.get_eps(xin, tb, bf["cond"], uncond_scale=uncond_scale, uncond_cond=bf["uncond_cond"])
-                _lib.check(lib.pf_randn_dev(npz.data_ptr(), n, self.seed, st.data_ptr(), ndraw - 1, off, stream), "pf_randn_dev")
-                _lib.check(lib.pf_ddpm_step_dev(xb.data_ptr(), e_t.data_ptr(), npz.data_ptr(), _lib.ptr(nq), _lib.ptr(bf["orig"]),
-                                                _lib.ptr(bf["mask"]), table.data_ptr(), st.data_ptr(), xb.data_ptr(), n, stream),
-                           "pf_ddpm_step_dev")
+                e_t = self.get_eps(xin, tb, bf["cond"], uncond_scale=uncond_scale, uncond_cond=bf["uncond_cond"], prep=bf["_prep"])
+                if rng:   # both draws inside the update kernel (draw order of the reference: known-region noise, then the p_sample noise)
+                    _lib.check(lib.pf_ddpm_step_rng_dev(xb.data_ptr(), e_t.data_ptr(), _lib.ptr(bf["orig"]), _lib.ptr(bf["mask"]), table.data_ptr(),
+                                                        st.data_ptr(), self.seed, off, xb.data_ptr(), n, stream), "pf_ddpm_step_rng_dev")
+                else:
+                    if nq is not None:
+                        _lib.check(lib.pf_randn_dev(nq.data_ptr(), n, self.seed, st.data_ptr(), 0, off, stream), "pf_randn_dev")
+                    _lib.check(lib.pf_randn_dev(npz.data_ptr(), n, self.seed, st.data_ptr(), ndraw - 1, off, stream), "pf_randn_dev")
+                    _lib.check(lib.pf_ddpm_step_dev(xb.data_ptr(), e_t.data_ptr(), npz.data_ptr(), _lib.ptr(nq), _lib.ptr(bf["orig"]),
+                                                    _lib.ptr(bf["mask"]), table.data_ptr(), st.data_ptr(), xb.data_ptr(), n, stream),
+                               "pf_ddpm_step_dev")
                 _lib.check(lib.pf_step_end(st.data_ptr(), ndraw, stream), "pf_step_end")
             return body
 
         key = ("ddpm", str(dev), float(uncond_scale), self.seed, off) + self._shape_key(**inputs)
-        ent = self._graph_for(key, inputs, make_body, lambda: self._set_state(st, t_start))
+        ent = self._graph_for(key, inputs, make_body, lambda: self._set_state(st, t_start), uncond_scale)
         g = ent["g"]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -229,11 +283,24 @@ class SDFSampler(DiffusionSampler):
 
     @torch.no_grad()
     def p_sample(self, x, c, t, step: int, repeat_noise: bool = False, temperature: float = 1.0,
-                 uncond_scale: float = 1.0, uncond_cond=None, cond_concat=None, return_x0: bool = True):
+                 uncond_scale: float = 1.0, uncond_cond=None, cond_concat=None, return_x0: bool = True, prep: Optional[dict] = None):
         """Returns (x_prev, x0, e_t) like the reference (sampler_sdf.py:80-171).  ``x0`` costs two extra elementwise
-        launches; the loops of this class (``sample`` / ``paint``) pass ``return_x0=False`` and get ``None`` for it."""
+        launches; the loops of this class (``sample`` / ``paint``) pass ``return_x0=False`` and get ``None`` for it.
+        ``prep``: the result of ``prepare(c, uncond_scale=, uncond_cond=)`` when the caller hoisted it."""
         step = int(step)
-        e_t = self._eps(x, c, step, uncond_scale, uncond_cond, cond_concat)
+        x = x.contiguous()
+        e_t = self._eps(x, c, step, uncond_scale, uncond_cond, cond_concat, prep)
+        coef = self._coef(step)
+        x_prev = torch.empty_like(x)
+        if step != 0 and not repeat_noise and temperature == 1.0 and self._rng_ok(x):
+            # the draw happens inside the update kernel: same values as randn() + pf_ddpm_step, one launch
+            per_sample = x.numel() // x.shape[0]
+            _lib.check(self._lib.pf_ddpm_step_rng(x.data_ptr(), e_t.data_ptr(), None, None, C.byref(coef), self.seed, 0, self._draws,
+                                                  self.sample_offset * per_sample, x_prev.data_ptr(), x.numel(), _lib.current_stream()),
+                       "pf_ddpm_step_rng")
+            self._draws += 1
+            x0 = (coef.c_recip * x - coef.c_recipm1 * e_t) if return_x0 else None
+            return x_prev, x0, e_t
         noise = None
         if step != 0:
             noise = self.randn((1, *x.shape[1:]) if repeat_noise else x.shape, x.device)
@@ -241,8 +308,6 @@ class SDFSampler(DiffusionSampler):
                 noise = noise.expand_as(x).contiguous()
             if temperature != 1.0:
                 noise = noise * temperature
-        coef = self._coef(step)
-        x_prev = torch.empty_like(x)
         _lib.check(self._lib.pf_ddpm_step(x.data_ptr(), e_t.data_ptr(), _lib.ptr(noise), None, None, None, C.byref(coef),
                                           x_prev.data_ptr(), x.numel(), _lib.current_stream()), "pf_ddpm_step")
         x0 = (coef.c_recip * x - coef.c_recipm1 * e_t) if return_x0 else None
@@ -262,9 +327,34 @@ class SDFSampler(DiffusionSampler):
     def sample(self, shape: List[int], cond, repeat_noise=False, temperature=1.0, x_last=None, uncond_scale=1.0,
                uncond_cond=None, t_start: int = 0):
         x = x_last if x_last is not None else self.randn(shape, cond.device)
+        prep = self.prepare(cond, uncond_scale=uncond_scale, uncond_cond=uncond_cond)
         for step in np.flip(self.time_steps)[t_start:]:
             x, _, _ = self.p_sample(x, cond, None, int(step), repeat_noise=repeat_noise, temperature=temperature,
-                                    uncond_scale=uncond_scale, uncond_cond=uncond_cond, return_x0=False)
+                                    uncond_scale=uncond_scale, uncond_cond=uncond_cond, return_x0=False, prep=prep)
+        return x
+
+    def repaint_step(self, x_t, cond, step: int, orig, mask, *, uncond_scale: float = 1.0, uncond_cond=None, cond_concat=None,
+                     prep: Optional[dict] = None):
+        """ONE iteration of ``paint``'s loop body with a known region (sampler_sdf.py:307-336): eps, the reverse step on the unknown
+        region, the forward-noised known region, the blend.  Two noise draws for step > 0 - known-region noise first, then the
+        ``p_sample`` noise, the reference's order - made inside the update kernel when the on-device generator is in use.
+        ``bench.py`` times exactly this method."""
+        lib, step, n = self._lib, int(step), x_t.numel()
+        coef = self._coef(step)
+        e_t = self._eps(x_t, cond, step, uncond_scale, uncond_cond, cond_concat, prep)
+        x = torch.empty_like(x_t)
+        if step > 0 and self._rng_ok(x_t):
+            _lib.check(lib.pf_ddpm_step_rng(x_t.data_ptr(), e_t.data_ptr(), orig.data_ptr(), mask.data_ptr(), C.byref(coef), self.seed,
+                                            self._draws, self._draws + 1, self.sample_offset * (n // x_t.shape[0]), x.data_ptr(), n,
+                                            _lib.current_stream()), "pf_ddpm_step_rng")
+            self._draws += 2
+            return x
+        # injected noise tape (parity tests) / step 0: the draws are tensors.  The tape's order is the reference's: q before the eps
+        # evaluation, p after it - randn() only counts draws, so drawing both here keeps the tape aligned
+        noise_q = self.randn(orig.shape, x_t.device) if step > 0 else None
+        noise_p = self.randn(x_t.shape, x_t.device) if step > 0 else None
+        _lib.check(lib.pf_ddpm_step(x_t.data_ptr(), e_t.data_ptr(), _lib.ptr(noise_p), _lib.ptr(noise_q), orig.data_ptr(), mask.data_ptr(),
+                                    C.byref(coef), x.data_ptr(), n, _lib.current_stream()), "pf_ddpm_step")
         return x
 
     @torch.no_grad()
@@ -281,23 +371,18 @@ class SDFSampler(DiffusionSampler):
         if self.graph and self.noise_fn is None and repaint_n == 1 and t_start >= 1:
             x = self._paint_graph(x, cond, int(t_start), orig, mask, uncond_scale, uncond_cond, cond_concat)
             steps = steps[-1:]          # step 0 (no noise) runs eagerly below
+        # everything the denoiser derives from (t, cond) alone, once for the whole loop
+        prep = self.prepare(cond, uncond_scale=uncond_scale, uncond_cond=uncond_cond)
         for step in steps:
             step = int(step)
-            coef = self._coef(step)
             if orig is None:
                 x, _, _ = self.p_sample(x, cond, None, step, uncond_scale=uncond_scale, uncond_cond=uncond_cond,
-                                        cond_concat=cond_concat, return_x0=False)
+                                        cond_concat=cond_concat, return_x0=False, prep=prep)
                 continue
             x_t = x
             for u in range(repaint_n):
-                # draw order matches the reference: known-region noise first, then the p_sample noise
-                noise_q = self.randn(orig.shape, x.device) if step > 0 else None
-                e_t = self._eps(x_t, cond, step, uncond_scale, uncond_cond, cond_concat)
-                noise_p = self.randn(x.shape, x.device) if step > 0 else None
-                x = torch.empty_like(x_t)
-                _lib.check(lib.pf_ddpm_step(x_t.data_ptr(), e_t.data_ptr(), _lib.ptr(noise_p), _lib.ptr(noise_q),
-                                            orig.data_ptr(), mask.data_ptr(), C.byref(coef), x.data_ptr(), n, stream()),
-                           "pf_ddpm_step")
+                x = self.repaint_step(x_t, cond, step, orig, mask, uncond_scale=uncond_scale, uncond_cond=uncond_cond,
+                                      cond_concat=cond_concat, prep=prep)
                 if u < repaint_n - 1 and step > 0:
                     noise = self.randn(orig.shape, x.device)
                     b = self.model.beta[step - 1]
@@ -345,26 +430,33 @@ class DDIMSampler(DiffusionSampler):
         off = self.sample_offset * (n // B)
         inputs = dict(x=x, cond=cond, orig=orig, mask=mask, orig_noise=orig_noise, uncond_cond=uncond_cond, cond_concat=cond_concat)
 
+        rng = noisy and self._rng_ok(x)
+
         def make_body(bf):
             xb, tb = bf["x"], torch.empty(B, dtype=torch.long, device=dev)
-            nz = torch.empty_like(xb) if noisy else None
+            nz = torch.empty_like(xb) if (noisy and not rng) else None
             bf["_keep"] = (tb, nz)
 
             def body():
                 stream = _lib.current_stream()
                 _lib.check(lib.pf_step_begin(st.data_ptr(), taus.data_ptr(), tb.data_ptr(), B, stream), "pf_step_begin")
                 xin = xb if bf["cond_concat"] is None else torch.cat([xb, bf["cond_concat"]], dim=1)
-                e_t = self.get_eps(xin, tb, bf["cond"], uncond_scale=uncond_scale, uncond_cond=bf["uncond_cond"])
-                if noisy:
-                    _lib.check(lib.pf_randn_dev(nz.data_ptr(), n, self.seed, st.data_ptr(), 0, off, stream), "pf_randn_dev")
-                _lib.check(lib.pf_ddim_step_dev(xb.data_ptr(), e_t.data_ptr(), _lib.ptr(nz), _lib.ptr(bf["orig"]), _lib.ptr(bf["orig_noise"]),
-                                                _lib.ptr(bf["mask"]), table.data_ptr(), st.data_ptr(), xb.data_ptr(), n, stream),
-                           "pf_ddim_step_dev")
+                e_t = self.get_eps(xin, tb, bf["cond"], uncond_scale=uncond_scale, uncond_cond=bf["uncond_cond"], prep=bf["_prep"])
+                if rng:
+                    _lib.check(lib.pf_ddim_step_rng_dev(xb.data_ptr(), e_t.data_ptr(), _lib.ptr(bf["orig"]), _lib.ptr(bf["orig_noise"]),
+                                                        _lib.ptr(bf["mask"]), table.data_ptr(), st.data_ptr(), self.seed, off, xb.data_ptr(), n,
+                                                        stream), "pf_ddim_step_rng_dev")
+                else:
+                    if noisy:
+                        _lib.check(lib.pf_randn_dev(nz.data_ptr(), n, self.seed, st.data_ptr(), 0, off, stream), "pf_randn_dev")
+                    _lib.check(lib.pf_ddim_step_dev(xb.data_ptr(), e_t.data_ptr(), _lib.ptr(nz), _lib.ptr(bf["orig"]), _lib.ptr(bf["orig_noise"]),
+                                                    _lib.ptr(bf["mask"]), table.data_ptr(), st.data_ptr(), xb.data_ptr(), n, stream),
+                               "pf_ddim_step_dev")
                 _lib.check(lib.pf_step_end(st.data_ptr(), 1 if noisy else 0, stream), "pf_step_end")
             return body
 
         key = ("ddim", str(dev), float(uncond_scale), self.seed, off, bool(noisy)) + self._shape_key(**inputs)
-        ent = self._graph_for(key, inputs, make_body, lambda: self._set_state(st, t_start))
+        ent = self._graph_for(key, inputs, make_body, lambda: self._set_state(st, t_start), uncond_scale)
         g = ent["g"]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -385,7 +477,19 @@ class DDIMSampler(DiffusionSampler):
     def _step(self, x, e_t, index, orig=None, orig_noise=None, mask=None, temperature=1.0, repeat_noise=False):
         coef = self._coef(index)
         noise = None
-        if float(self.ddim_sigma[index]) != 0.0:
+        noisy = float(self.ddim_sigma[index]) != 0.0
+        if noisy and not repeat_noise and temperature == 1.0 and self._rng_ok(x):
+            # the step's draw happens inside the update kernel (same values as randn() + pf_ddim_step)
+            draw = self._draws
+            self._draws += 1
+            if orig is not None and orig_noise is None:   # reference: a fresh q_sample noise per step, drawn after p_sample's
+                orig_noise = self.randn(orig.shape, x.device)
+            out = torch.empty_like(x)
+            _lib.check(self._lib.pf_ddim_step_rng(x.data_ptr(), e_t.data_ptr(), _lib.ptr(orig), _lib.ptr(orig_noise), _lib.ptr(mask),
+                                                  C.byref(coef), self.seed, draw, self.sample_offset * (x.numel() // x.shape[0]),
+                                                  out.data_ptr(), x.numel(), _lib.current_stream()), "pf_ddim_step_rng")
+            return out, coef
+        if noisy:
             noise = self.randn((1, *x.shape[1:]) if repeat_noise else x.shape, x.device)
             if repeat_noise:
                 noise = noise.expand_as(x).contiguous()
@@ -408,8 +512,8 @@ class DDIMSampler(DiffusionSampler):
 
     @torch.no_grad()
     def p_sample(self, x, c, t, step: int, index: int, *, repeat_noise=False, temperature=1.0, uncond_scale=1.0,
-                 uncond_cond=None, cond_concat=None):
-        e_t = self._eps(x, c, int(step), uncond_scale, uncond_cond, cond_concat)
+                 uncond_cond=None, cond_concat=None, prep: Optional[dict] = None):
+        e_t = self._eps(x, c, int(step), uncond_scale, uncond_cond, cond_concat, prep)
         x_prev, pred_x0 = self.get_x_prev_and_pred_x0(e_t, index, x, temperature=temperature, repeat_noise=repeat_noise)
         return x_prev, pred_x0, e_t
 
@@ -428,9 +532,10 @@ class DDIMSampler(DiffusionSampler):
                t_start: int = 0):
         x = x_last if x_last is not None else self.randn(shape, cond.device)
         time_steps = np.flip(self.time_steps)[t_start:]
+        prep = self.prepare(cond, uncond_scale=uncond_scale, uncond_cond=uncond_cond)
         for i, step in enumerate(time_steps):
             index = len(time_steps) - i - 1
-            e_t = self._eps(x, cond, int(step), uncond_scale, uncond_cond, None)
+            e_t = self._eps(x, cond, int(step), uncond_scale, uncond_cond, None, prep)
             x, _ = self._step(x, e_t, index, temperature=temperature, repeat_noise=repeat_noise)
         return x
 
@@ -448,9 +553,10 @@ class DDIMSampler(DiffusionSampler):
             if not bool(nonzero.any()) or bool(nonzero.all()):    # a mixed range would need a per-step decision on the host
                 return self._paint_graph(x, cond, int(t_start), orig, mask, orig_noise, uncond_scale, uncond_cond, cond_concat,
                                          noisy=bool(nonzero.all()))
+        prep = self.prepare(cond, uncond_scale=uncond_scale, uncond_cond=uncond_cond)
         for i, step in enumerate(time_steps):
             index = len(time_steps) - i - 1
-            e_t = self._eps(x, cond, int(step), uncond_scale, uncond_cond, cond_concat)
+            e_t = self._eps(x, cond, int(step), uncond_scale, uncond_cond, cond_concat, prep)
             # x_prev and the known-region blend (fixed orig_noise, sampler_ddim.py:355-359) in one kernel
             x, _ = self._step(x, e_t, index, orig=orig, orig_noise=orig_noise, mask=mask)
         return x

@@ -110,7 +110,8 @@ class UNetModel:
 
     # ---- forward --------------------------------------------------------------------------------
     def workspace(self, batch: int, n_cond: int) -> torch.Tensor:
-        key = (batch, n_cond, self._lib.pf_unet_get_precision(self._h))  # tile choice (and buffer sizes) depend on the mode
+        # tile choice (and buffer sizes) depend on the arithmetic mode and on the plan options
+        key = (batch, n_cond, self._lib.pf_unet_get_precision(self._h)) + tuple(self._lib.pf_unet_get_option(self._h, o) for o in range(3))
         if self._ws is None or self._ws_key != key:
             nbytes = self._lib.pf_unet_workspace_bytes(self._h, batch, n_cond)
             if self._ws is None or self._ws.numel() < nbytes:
@@ -119,7 +120,45 @@ class UNetModel:
             self._ws_key = key
         return self._ws
 
-    def forward(self, x: torch.Tensor, time_steps: torch.Tensor, cond: torch.Tensor, out: Optional[torch.Tensor] = None):
+    # ---- step-invariant prefix (hoisted out of a sampler's loop; include/pfhip.h pf_unet_prepared) ---------------
+    def prepare_time(self, n_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[n_rows, W] table: row r = the additive time biases of every ResBlock for time-step VALUE r - what ``forward`` derives
+        from ``t == r`` through ``time_embed`` and the ``emb_layers`` (unet.py:181-182, 286-289).  Depends on the weights only."""
+        if self._blob_dev is None:
+            raise RuntimeError("UNetModel.prepare_time: weights not loaded")
+        w = int(self._lib.pf_unet_time_bias_width(self._h))
+        if out is None:
+            out = torch.empty(n_rows, w, dtype=torch.float32, device=self.device)
+        assert out.shape == (n_rows, w) and out.is_contiguous()
+        scratch = torch.empty(n_rows * 4 * self.cfg.channels, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.pf_unet_prepare_time(self._h, n_rows, out.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,
+                                                  _lib.current_stream()), "pf_unet_prepare_time")
+        return out
+
+    def prepare_cond(self, cond: torch.Tensor, out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """[B, W] collapsed cross-attention biases ``to_out(to_v(cond))`` of every transformer block for ONE context token
+        (unet_attention.py:186-212 with softmax over a single key); ``None`` when ``cond`` has several tokens (general path)."""
+        if self._blob_dev is None:
+            raise RuntimeError("UNetModel.prepare_cond: weights not loaded")
+        w = int(self._lib.pf_unet_cross_bias_width(self._h))
+        if cond.dim() != 3 or cond.shape[1] != 1 or w == 0:
+            return None
+        if cond.shape[2] != self.cfg.d_cond:
+            raise RuntimeError(f"UNetModel.prepare_cond: cond has shape {tuple(cond.shape)}, expected [B,1,{self.cfg.d_cond}]")
+        cond = cond.contiguous().float()
+        B = cond.shape[0]
+        if out is None:
+            out = torch.empty(B, w, dtype=torch.float32, device=cond.device)
+        assert out.shape == (B, w) and out.is_contiguous()
+        scratch = torch.empty(B * w, dtype=torch.float32, device=cond.device)
+        _lib.check(self._lib.pf_unet_prepare_cond(self._h, cond.data_ptr(), B, out.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,
+                                                  _lib.current_stream()), "pf_unet_prepare_cond")
+        return out
+
+    def forward(self, x: torch.Tensor, time_steps: torch.Tensor, cond: torch.Tensor, out: Optional[torch.Tensor] = None, *,
+                time_table: Optional[torch.Tensor] = None, cross_bias: Optional[torch.Tensor] = None):
+        """``time_table`` / ``cross_bias``: results of ``prepare_time`` / ``prepare_cond(cond)`` - the caller vouches that they
+        belong to these weights and this ``cond``; either may be ``None`` (computed here).  Bit-identical either way."""
         if self._blob_dev is None:
             raise RuntimeError("UNetModel.forward: weights not loaded")
         B = x.shape[0]
@@ -134,9 +173,18 @@ class UNetModel:
         ws = self.workspace(B, n_cond)
         if out is None:
             out = torch.empty(B, self.cfg.out_channels, self.img_h, self.img_w, dtype=torch.float32, device=x.device)
-        _lib.check(self._lib.pf_unet_forward(self._h, x.data_ptr(), t.data_ptr(), cond.data_ptr(), B, n_cond,
-                                             out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream()),
-                   "pf_unet_forward")
+        prep = None
+        if time_table is not None or cross_bias is not None:
+            prep = _lib.UNetPrepared()
+            if time_table is not None:
+                assert time_table.dtype == torch.float32 and time_table.is_contiguous() and time_table.device == x.device
+                prep.time_table, prep.n_time_rows = time_table.data_ptr(), time_table.shape[0]
+            if cross_bias is not None:
+                assert n_cond == 1 and cross_bias.shape[0] == B and cross_bias.is_contiguous() and cross_bias.device == x.device
+                prep.cross_bias = cross_bias.data_ptr()
+        _lib.check(self._lib.pf_unet_forward_prepared(self._h, x.data_ptr(), t.data_ptr(), cond.data_ptr(), B, n_cond,
+                                                      None if prep is None else C.byref(prep), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                      _lib.current_stream()), "pf_unet_forward")
         return out
 
     __call__ = forward
@@ -152,6 +200,19 @@ class UNetModel:
     def precision(self) -> str:
         return ["f32", "bf16x3"][self._lib.pf_unet_get_precision(self._h)]
 
+    # ---- plan options (which of two equivalent kernel forms the plan launches; include/pfhip.h PF_OPT_*) --------
+    _OPTS = {"mlp_fused": _lib.OPT_MLP_FUSED, "attn_wide": _lib.OPT_ATTN_WIDE, "conv_t16": _lib.OPT_CONV_T16}
+
+    def set_option(self, name: str, value: Optional[bool]):
+        """``None`` = automatic (the default), ``False`` / ``True`` = never / always (where the form exists)."""
+        v = _lib.OPT_AUTO if value is None else int(bool(value))
+        _lib.check(self._lib.pf_unet_set_option(self._h, self._OPTS[name], v), "pf_unet_set_option")
+        return self
+
+    def get_option(self, name: str) -> Optional[bool]:
+        v = self._lib.pf_unet_get_option(self._h, self._OPTS[name])
+        return None if v < 0 else bool(v)
+
     # ---- profiling ------------------------------------------------------------------------------
     def set_profiling(self, on: bool):
         _lib.check(self._lib.pf_unet_set_profiling(self._h, int(on)))
@@ -164,7 +225,9 @@ class UNetModel:
         n = _lib.check(self._lib.pf_unet_profile_read(self._h, kind, ms, fl, cap))
         return [(kind[i], ms[i], fl[i]) for i in range(n)]
 
-    def n_launches(self, batch: int, n_cond: int = 1) -> int:
+    def n_launches(self, batch: int, n_cond: int = 1, prepared: bool = False) -> int:
+        if prepared:
+            return int(self._lib.pf_unet_n_launches_prepared(self._h, batch, n_cond, 1, 1))
         return int(self._lib.pf_unet_n_launches(self._h, batch, n_cond))
 
 
@@ -196,7 +259,7 @@ class LatentDiffusion:
     def eval(self):
         return self
 
-    def forward(self, x: torch.Tensor, t: torch.Tensor, context: torch.Tensor):
-        return self.eps_model(x, t, context)
+    def forward(self, x: torch.Tensor, t: torch.Tensor, context: torch.Tensor, **prepared):
+        return self.eps_model(x, t, context, **prepared)
 
     __call__ = forward

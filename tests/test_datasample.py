@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from polyffusion_amd import datasample, synth
 
@@ -39,3 +40,70 @@ def test_npz_round_trip_and_edges(tmp_path):
     e = dict(d)
     e["db_pos_filter"] = np.zeros_like(d["db_pos_filter"])
     assert len(datasample.DataSample(e)) == 0
+
+
+def _pop909_file(tmp_path, seed=0):
+    """A synthetic song in the POP909 .npz layout ref:data/dataset.py:70-84 reads: per-track note matrices and start tables."""
+    import os, pickle
+    rng = np.random.default_rng(seed)
+
+    def track(n):
+        on = np.sort(rng.integers(0, 512, n))
+        nm = np.stack([on, rng.integers(30, 90, n), rng.integers(1, 8, n), np.full(n, 80), np.zeros(n, int)], 1)
+        return nm, {b: int(np.searchsorted(on, b)) for b in range(0, 513)}
+
+    ts = [track(60), track(30), track(90)]
+    notes, st = np.empty(3, dtype=object), np.empty(3, dtype=object)
+    for i, (a, b) in enumerate(ts):
+        notes[i], st[i] = a, b
+    db = np.arange(0, 512, 16)
+    filt = np.ones(len(db), bool)
+    filt[-8:] = False
+    chord = np.zeros((128, 14), int)
+    chord[:, 0], chord[:, 13] = rng.integers(0, 12, 128), rng.integers(0, 12, 128)
+    os.makedirs(tmp_path / "data")
+    np.savez(tmp_path / "data" / "7.npz", notes=notes, start_table=st, db_pos=db, db_pos_filter=filt, chord=chord)
+    with open(tmp_path / "pop909.pickle", "wb") as f:
+        pickle.dump((["1.npz"], ["7.npz"]), f)
+    return ts, db, filt, chord
+
+
+def test_pop909_song_file_tracks(tmp_path):
+    """DataSampleNpz (ref:data/dataset.py:27-253; parity unpinned - the dataset is not shipped): one track alone equals DataSample on
+    that track's rows, several tracks give the union of their piano rolls, and the validation half of the split pickle is what
+    --from_dataset indexes (ref:inference_sdf.py:95-105)."""
+    from polyffusion_amd import datasample as ds
+    ts, db, filt, chord = _pop909_file(tmp_path)
+    per_track = []
+    for i, (nm, table) in enumerate(ts):
+        one, fn = ds.choose_song_from_val_dl("pop909", 0, (i,), str(tmp_path / "data"), str(tmp_path))
+        assert fn == "7.npz"
+        ref = ds.DataSample(dict(notes=nm, start_table=table, db_pos=db, db_pos_filter=filt, chord=chord)).get_whole_song_data()
+        got = one.get_whole_song_data()
+        assert all(torch.equal(a, b) for a, b in zip(got, ref))
+        per_track.append(got[0])
+    allt = ds.DataSampleNpz("7.npz", (0, 1, 2), str(tmp_path / "data")).get_whole_song_data()
+    assert torch.equal(allt[0], torch.stack(per_track).amax(0)) and allt[2].shape == (3, 32, 36)
+    asked = []
+    s, _ = ds.choose_song_from_val_dl("pop909", None, (0,), str(tmp_path / "data"), str(tmp_path), ask=lambda q: asked.append(q) or "0")
+    assert asked and len(s) == int(filt.sum())
+    with pytest.raises(NotImplementedError):
+        ds.choose_song_from_val_dl("lakh", 0, split_dir=str(tmp_path))
+
+
+def test_split_pickle_admits_only_name_lists(tmp_path):
+    import os, pickle
+    from polyffusion_amd import datasample as ds
+    with open(tmp_path / "bad.pickle", "wb") as f:
+        pickle.dump((["a.npz"], [os.path.join]), f)           # a global inside: refused, never resolved
+    with pytest.raises(pickle.UnpicklingError):
+        ds.load_split(str(tmp_path / "bad.pickle"))
+    with open(tmp_path / "odd.pickle", "wb") as f:
+        pickle.dump({"train": []}, f)
+    with pytest.raises(ValueError):
+        ds.load_split(str(tmp_path / "odd.pickle"))
+    # the reference's own split files load (they are lists of names): checked where the reference checkout exists
+    ref = "/root/reference/data/train_split_pnt/pop909.pickle"
+    if os.path.exists(ref):
+        tr, va = ds.load_split(ref)
+        assert len(tr) == 797 and len(va) == 89 and va[0] == "258.npz"

@@ -170,10 +170,7 @@ def test_split_k_small_m_layers(lib, B, H, W, c0, c1, cout):
 def test_qkv_planes_and_bf16x3_attention(lib, B, L, H, wide, monkeypatch):
     """q|k|v projection (LayerNorm prologue) written as pre-split bf16 hi/lo planes, consumed by the bf16x3 attention - in its
     128-query form, in the 256-query form (two query fragments per wave), and at the bench shape with the launcher's own choice."""
-    if wide is None:
-        monkeypatch.delenv("PF_ATTN_WIDE", raising=False)
-    else:
-        monkeypatch.setenv("PF_ATTN_WIDE", wide)
+    form = -1 if wide is None else int(wide)   # pf_attention_bf16x3's `form`: auto / 128-query / 256-query workgroups
     c = H * 64
     x = rnd((B, L, c), 81) * 1.3 + 0.2
     gamma, beta = 1 + 0.1 * rnd((c,), 82), 0.1 * rnd((c,), 83)
@@ -194,7 +191,7 @@ def test_qkv_planes_and_bf16x3_attention(lib, B, L, H, wide, monkeypatch):
     qrec = (pl[0] + pl[1]).view(B, L, c)
     assert (qrec - qkv[..., :c]).abs().max() < 3e-4
     out = torch.empty(B, L, c, device="cuda")
-    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, None, B, H, L, _lib.current_stream()))
+    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, None, B, H, L, form, _lib.current_stream()))
     torch.cuda.synchronize()
     err = (out.cpu() - ref).abs().max().item()
     assert err < 3e-4, err
@@ -248,7 +245,7 @@ def test_planes_gemm_chain(lib, B, L, k, n):
 @pytest.mark.parametrize("L,wide", [(256, "0"), (256, "1"), (512, "1")])
 def test_attention_planes_output(lib, L, wide, monkeypatch):
     """hi/lo plane output (the operand of the to_out planes GEMM) from both forms of the kernel."""
-    monkeypatch.setenv("PF_ATTN_WIDE", wide)
+    form = int(wide)
     B, H = 2, 4
     c = H * 64
     qkv = rnd((B, L, 3 * c), 101)
@@ -261,7 +258,7 @@ def test_attention_planes_output(lib, L, wide, monkeypatch):
     run_conv(lib, x0=dev(qkv), c0=3 * c, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, eye), n=3 * c,
              out=dummy, ld_out=3 * c, precision=1, qkv_planes=planes)
     op = torch.zeros(B * L * c, device="cuda")
-    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), None, c, op.data_ptr(), B, H, L, _lib.current_stream()))
+    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), None, c, op.data_ptr(), B, H, L, form, _lib.current_stream()))
     torch.cuda.synchronize()
     pl = op.view(torch.bfloat16).float().cpu().view(2, B, L, c)
     assert (pl[0] + pl[1] - ref).abs().max().item() < 3e-4
@@ -272,7 +269,7 @@ def test_attention_running_maximum_extremes(lib, wide, monkeypatch):
     """Scores whose row maxima keep growing from tile to tile (key norms ramp up along the sequence: the reference exponent of the
     256-query form moves several times per row, the 128-query form rescales on every tile), rows dominated by one late key, and rows
     whose scores are all far below the first tile's - against the fp32 softmax."""
-    monkeypatch.setenv("PF_ATTN_WIDE", wide)
+    form = int(wide)
     B, L, H = 1, 1024, 4
     c = H * 64
     g = torch.Generator().manual_seed(5)
@@ -289,7 +286,7 @@ def test_attention_running_maximum_extremes(lib, wide, monkeypatch):
     run_conv(lib, x0=dev(qkv), c0=3 * c, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, torch.eye(3 * c)), n=3 * c,
              out=dummy, ld_out=3 * c, precision=1, qkv_planes=planes)
     out = torch.empty(B, L, c, device="cuda")
-    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, None, B, H, L, _lib.current_stream()))
+    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, None, B, H, L, form, _lib.current_stream()))
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
     err = (out.cpu() - ref).abs().max().item()
@@ -321,7 +318,7 @@ def test_ln_planes_feeds_the_projection(lib, B, L, H):
     run_conv(lib, x0=lnp, c0=c, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, w), n=3 * c, out=dummy, ld_out=3 * c,
              precision=1, a_planes=1, qkv_planes=planes)
     out = torch.empty(B, L, c, device="cuda")
-    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, None, B, H, L, _lib.current_stream()))
+    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), out.data_ptr(), c, None, B, H, L, -1, _lib.current_stream()))
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max().item() < 3e-4
 

@@ -214,7 +214,7 @@ def test_cli_concat_blurry_params(tmp_path):
     # without the image to blur the CLI says so; with the shipped sdf_concat preset (in_channels 3) the 2-channel blurry image does not fit
     # the denoiser - in the reference (cat + conv shape error) as here
     np.savez(tmp_path / "cond2.npz", chord=synth.chords(n, 32))
-    with pytest.raises(SystemExit, match="needs the image to blur"):
+    with pytest.raises(SystemExit, match="image to blur"):
         inference_sdf.main(argv[:4] + [str(tmp_path / "cond2.npz")] + argv[5:])
 
 

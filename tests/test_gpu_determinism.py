@@ -107,7 +107,7 @@ def test_attention_is_bit_reproducible(L, B, wide, monkeypatch):
     """Both forms of the bf16x3 self-attention (hand-counted LDS / direct-to-LDS waits, hidden fragment loads, a static filler
     schedule) repeated on one input: every repeat must give the same bits, in both output formats."""
     from polyffusion_amd import _lib
-    monkeypatch.setenv("PF_ATTN_WIDE", wide)
+    form = int(wide)
     lib = _lib.load()
     H, c = 4, 256
     g = torch.Generator().manual_seed(L + B)
@@ -118,7 +118,7 @@ def test_attention_is_bit_reproducible(L, B, wide, monkeypatch):
         for _ in range(24):
             out = torch.zeros(B, L, c, device="cuda")
             args = (None, c, out.data_ptr()) if as_planes else (out.data_ptr(), c, None)
-            _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), args[0], args[1], args[2], B, H, L, st))
+            _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), args[0], args[1], args[2], B, H, L, form, st))
             outs.append(out)
         torch.cuda.synchronize()
         bad = sum(not torch.equal(outs[0], o) for o in outs[1:])

@@ -119,58 +119,3 @@ def test_fused_mlp_with_chained_proj_out(lib, B, L):
         _lib.check(lib.pf_mlp_geglu_proj_fused(xd.data_ptr(), B, L, gd.data_ptr(), bd.data_ptr(), 1e-5, p1.data_ptr(), b1d.data_ptr(), p2.data_ptr(),
                                                b2d.data_ptr(), p3.data_ptr(), b3d.data_ptr(), xind.data_ptr(), o3.data_ptr(), None, st))
         assert torch.equal(o3, out)
-
-
-@pytest.mark.parametrize("B,L,tail", [(2, 1024, True), (16, 1024, True), (3, 128, False), (16, 1024, False)])
-def test_transformer_tail_fused(lib, B, L, tail):
-    """pf_transformer_tail_fused: attn1.to_out + residual, norm3, GeGLU feed-forward + residual (and proj_out + block input) in one launch
-    (unet_attention.py:115-124, 77-79), against torch and - bit for bit - against the planes GEMM + fused feed-forward pair it replaces."""
-    import ctypes as CT
-    from test_gpu_bf16x3 import _split_planes
-    w1, b1, w2, b2, gamma, beta, w1i, b1i = _weights(500)
-    wo, bo = rnd((C, C), 507, C ** -0.5), rnd((C,), 508, 0.1)
-    w3, b3 = rnd((C, C), 509, C ** -0.5), rnd((C,), 510, 0.1)
-    att = rnd((B, L, C), 511 + B)
-    att = (att.to(torch.bfloat16).float() + (att - att.to(torch.bfloat16).float()).to(torch.bfloat16).float())   # exactly a plane pair
-    x0, xin, cross = rnd((B, L, C), 520 + B), rnd((B, L, C), 530 + B), rnd((B, 3 * C), 540 + B, 0.3)
-    x1 = F.linear(att, wo, bo) + cross[:, None, C:2 * C] + x0
-    h = F.linear(F.layer_norm(x1, (C,), gamma, beta, 1e-5), w1, b1)
-    x2 = x1 + F.linear(h[..., :HID] * F.gelu(h[..., HID:]), w2, b2)
-    ref = F.linear(x2, w3, b3) + xin if tail else x2
-
-    ap, x0d, xind, crossd, gd, bd = _split_planes(att), dev(x0), dev(xin), dev(cross), dev(gamma), dev(beta)
-    po, p1, p2, p3 = pack3(lib, wo), pack3(lib, w1i), pack3(lib, w2), pack3(lib, w3)
-    bod, b1d, b2d, b3d = dev(bo), dev(b1i), dev(b2), dev(b3)
-    x1buf = torch.zeros(B, L, C, device="cuda")
-    out = torch.empty(B, L, C, device="cuda")
-    stats = torch.zeros(B, L // 64, C, 2, device="cuda")
-    a = _lib.TBlockTailArgs()
-    a.attn_planes, a.wo, a.bo, a.cross_bias, a.ld_cross_bias, a.x0, a.x1 = ap.data_ptr(), po.data_ptr(), bod.data_ptr(), crossd.data_ptr() + C * 4, 3 * C, \
-        x0d.data_ptr(), x1buf.data_ptr()
-    a.batch, a.l, a.ln_gamma, a.ln_beta, a.ln_eps = B, L, gd.data_ptr(), bd.data_ptr(), 1e-5
-    a.w1, a.b1, a.w2, a.b2 = p1.data_ptr(), b1d.data_ptr(), p2.data_ptr(), b2d.data_ptr()
-    if tail:
-        a.w3, a.b3, a.res3, a.stats3 = p3.data_ptr(), b3d.data_ptr(), xind.data_ptr(), stats.data_ptr()
-    a.out = out.data_ptr()
-    st = _lib.current_stream()
-    _lib.check(lib.pf_transformer_tail_fused(CT.byref(a), st), "pf_transformer_tail_fused")
-    torch.cuda.synchronize()
-    assert (x1buf.cpu() - x1).abs().max().item() < TOL_OP and (out.cpu() - ref).abs().max().item() < TOL_OP
-    # the pair it replaces
-    t1 = torch.empty(B, L, C, device="cuda")
-    run_conv(lib, x0=ap, c0=C, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=po, n=C, bias=bod, sbias=crossd[:, C:], ld_sbias=3 * C, res=x0d,
-             ld_res=C, out=t1, ld_out=C, precision=1, a_planes=1)
-    assert torch.equal(t1, x1buf)
-    out2 = torch.empty(B, L, C, device="cuda")
-    if tail:
-        _lib.check(lib.pf_mlp_geglu_proj_fused(t1.data_ptr(), B, L, gd.data_ptr(), bd.data_ptr(), 1e-5, p1.data_ptr(), b1d.data_ptr(), p2.data_ptr(),
-                                               b2d.data_ptr(), p3.data_ptr(), b3d.data_ptr(), xind.data_ptr(), out2.data_ptr(), None, st))
-    else:
-        _lib.check(lib.pf_mlp_geglu_fused(t1.data_ptr(), B, L, gd.data_ptr(), bd.data_ptr(), 1e-5, p1.data_ptr(), b1d.data_ptr(), p2.data_ptr(),
-                                          b2d.data_ptr(), out2.data_ptr(), None, st))
-    assert torch.equal(out, out2), f"chained and unchained differ by {(out - out2).abs().max().item():.3e}"
-    for _ in range(3):
-        o3 = torch.empty_like(out)
-        a.out = o3.data_ptr()
-        _lib.check(lib.pf_transformer_tail_fused(CT.byref(a), st))
-        assert torch.equal(o3, out)

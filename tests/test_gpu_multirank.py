@@ -36,6 +36,22 @@ def test_bench_two_ranks():
     assert abs(d["value"] - 2 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) / d["value"] < 1e-3
 
 
+def test_bench_bare_command_spawns_its_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (how a driver that mirrors its 1-GPU command would call it): bench.py re-executes
+    itself under torch.distributed.run, one rank per GPU, and still prints exactly one JSON line with both ranks in it."""
+    env = dict(os.environ, PF_DIST_BACKEND="gloo", PF_LOCAL_DEVICE="0", PYTHONPATH=REPO)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--windows", "2", "--profile-steps", "0",
+                          "--fp32-steps", "0", "--small-batch-steps", "0"], capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["devices_seen"] == [0, 0] and d["config"]["global_batch"] == 32
+    assert d["windows"] == 2 and len(d["windows_ms_per_step"]) == 2 and d["config"]["weight_broadcast_s"] >= 0
+
+
 def test_cli_two_ranks_equal_one_rank(tmp_path):
     from ckpt_fixture import full_state, write_legacy_pt
     from polyffusion_amd.arch import UNetConfig
