@@ -295,6 +295,9 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="arithmetic of the dense contractions: exact fp32 MFMA, or the error-compensated bf16x3 split")
     ap.add_argument("--dump-launches", action="store_true", help="print one line per kernel launch of a profiled step (stderr)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=0|1",
+                    help="pin a plan option of the UNet handle (pf_unet_set_option: mlp_fused, attn_wide, conv_t16, gn_fold) for A/B runs; "
+                         "the default line runs with every option automatic")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -318,6 +321,9 @@ def main():
     model, bcast_s = build_model(params, rank, world)
     unet = model.ldm.eps_model
     unet.set_precision(args.precision)
+    for o in args.option:
+        name, val = o.split("=")
+        unet.set_option(name, bool(int(val)))
     ranks_seen, devices_seen = pfdist.ranks_seen()
 
     # per-rank batch of 16: global sample indices [rank*16, rank*16+16) -> noise streams independent of N
@@ -372,6 +378,7 @@ def main():
         "path_tflops": round(f_eval * BATCH * world * args.steps / elapsed / 1e12, 3),
         "path_frac_of_f32_mfma_peak": round(f_eval * BATCH * args.steps / elapsed / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
         "path_flops_per_sample_eval": f_eval,
+        "plan_options": {n: unet.get_option(n) for n in ("mlp_fused", "attn_wide", "conv_t16", "gn_fold")},
         "precision_note": ("dense contractions on the bf16 matrix pipe as an error-compensated split (3 MFMAs per product, fp32 accumulate); "
                            "UNet max-abs-diff vs the reference 5.2e-5 (contract 1e-3)") if args.precision == "bf16x3"
         else "dense contractions on the fp32 matrix pipe (exact fp32 FMA chains)",
