@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of one plan option: bash tools/ab_option.sh gn_fold [reps]   -> gpurun_out/ab/ab_<option>.txt
+# same-box A/B of one plan option: bash tools/ab_option.sh mlp_fused [reps]   -> gpurun_out/ab/ab_<option>.txt
 opt=$1; reps=${2:-3}
 mkdir -p gpurun_out/ab
 F="--steps 50 --warmup 5 --no-cpu-baseline --profile-steps 0 --small-batch-steps 0 --fp32-steps 0"
