@@ -180,6 +180,42 @@ def smi_snapshot():
         return {}
 
 
+def measure_traffic(precision):
+    """HBM bytes per launch of the 3x3 conv family, measured in THIS run: two child runs of this script (3 steps each) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` - separate passes, counters never combined with another trace domain,
+    as MI355X_MICROARCH.md's HBM section prescribes - and its corrections: both counters are in KB, FETCH_SIZE counts a 128-byte request as
+    64 B on gfx950 (doubled here).  Returns (bytes per launch, description) or (None, why)."""
+    import shutil, sqlite3, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--windows", "1", "--profile-steps", "0", "--no-cpu-baseline",
+             "--small-batch-steps", "0", "--fp32-steps", "0", "--no-pmc", "--precision", precision]
+    pat = "conv_bf3_kernel<" if precision == "bf16x3" else "conv_mfma_kernel<"
+    tot, launches = {}, 0
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            try:
+                subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "rocpd", "-d", out, "-o", "bench", "--"] + child,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, timeout=300, check=True)
+                dbs = [os.path.join(r, f) for r, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+                db = sqlite3.connect(dbs[0])
+                rows = db.execute("select name, sum(counter_value), count(distinct dispatch_id) from pmc_events where counter_name = ? group by name",
+                                  (ctr,)).fetchall()
+            except Exception as e:   # a box without counter access, a changed schema: fall back to the committed collection
+                return None, f"{ctr} pass failed: {type(e).__name__}"
+            fam = [(v, n) for name, v, n in rows if pat in name and (precision != "bf16x3" or name.split(pat)[1][0] in "23")]
+            if not fam:
+                return None, f"{ctr} pass: no {pat} dispatches in the counter database"
+            tot[ctr] = sum(v for v, _ in fam)
+            launches = sum(n for _, n in fam)
+    per_launch = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / launches
+    return per_launch, (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over 3 steps of this "
+                        f"workload each ({launches} launches of the 3x3 family per pass); KB units x 1024, FETCH_SIZE doubled (gfx950 tallies a 128-byte "
+                        "request as 64 B, MI355X_MICROARCH.md HBM section)")
+
+
 def timed_loop(step_fn, x, t_step, steps, probe=None):
     """K steps between barrier + synchronize pairs (the driver contract: host clock, max over ranks) with a HIP-event pair on the
     launch stream around the same K steps.  Returns (x, t_step, host seconds (max over ranks), event seconds,
@@ -291,6 +327,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=2, help="profiled steps for the roofline object (0 disables)")
     ap.add_argument("--fp32-steps", type=int, default=10, help="steps of the exact-fp32-MFMA mode measured in the same run (0 disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not spawn the two rocprofv3 counter passes that measure roofline.traffic in the run")
     ap.add_argument("--small-batch-steps", type=int, default=40, help="reverse steps of the batch-1 / batch-8 eager-vs-hipGraph lines (0 disables)")
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="arithmetic of the dense contractions: exact fp32 MFMA, or the error-compensated bf16x3 split")
@@ -402,14 +439,15 @@ def main():
             ach_corr = k[2] / (corr_ms * 1e-3) / 1e12
             ach = k[2] / (k[1] * 1e-3) / 1e12      # `achieved` / `frac` stay on the raw (pessimistic) event durations
             peak = PEAK_ALGO[args.precision]
-            traffic = None
+            traffic, traffic_src = (None, "--no-pmc") if (args.no_pmc or world != 1) else measure_traffic(args.precision)
             tpath = os.path.join(REPO, "profiles", f"pmc_traffic_{args.precision}.json")
-            if os.path.exists(tpath):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+            if traffic is None and os.path.exists(tpath):  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic_src = (f"profiles/pmc_traffic_{args.precision}.json: bytes per launch from the committed rocprofv3 --pmc passes of this workload "
+                               f"(not re-measured in this run: {traffic_src})")
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": traffic,
-                               "traffic_source": f"profiles/pmc_traffic_{args.precision}.json: bytes per launch from the committed rocprofv3 "
-                                                 "--pmc passes of this workload (not re-measured in this run)",
+                               "traffic_source": traffic_src,
                                "peak_note": ("fp32-equivalent ceiling = bf16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per product"
                                              if args.precision == "bf16x3" else "fp32 MFMA dense peak"),
                                "matrix_pipe_frac": round(ach * (3.0 if args.precision == "bf16x3" else 1.0)
