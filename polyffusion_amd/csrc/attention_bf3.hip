@@ -84,15 +84,16 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
   // V^T hi, V^T lo), row (u%512)/8, slot u%8
   const __bf16* kbase = p.planes + 2 * MC + (size_t)b * L * C + h * DH;           // + plane*MC + key*C + d
   const __bf16* vbase = p.planes + 4 * MC + ((size_t)b * p.H + h) * DH * L;       // + plane*MC + d*L + key
+  // (buffer-form direct-to-LDS loads, dma16 of conv_common.h; the lo plane lies MC elements behind the hi plane: with 2 * MC bytes >= 2 GiB
+  // the launcher refuses, so every offset fits the 32-bit offset registers)
+  const __amdgpu_buffer_rsrc_t rsK = dma_resource(kbase), rsV = dma_resource(vbase);
   auto issue_piece = [&](int t, int stage, int j) {
     const int u = tid + j * NT;
     const int arr = u >> 9, row = (u & 511) >> 3;
     const int src_slot = (u & 7) ^ ((row >> 1) & 7);     // swizzle on the SOURCE side; the LDS image stays lane-linear
-    const __bf16* gp = (arr < 2) ? kbase + (size_t)(arr & 1) * MC + (size_t)(t * KT + row) * C + src_slot * 8
-                                 : vbase + (size_t)(arr & 1) * MC + (size_t)row * L + t * KT + src_slot * 8;
     __bf16* lp = sm + stage * STAGE + (j * NT + wave * 64) * 8;   // wave-uniform; the hardware adds lane*16 B
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                     (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+    if (arr < 2) dma16(rsK, (int)(((size_t)(arr & 1) * MC + (size_t)row * C + src_slot * 8) * 2), t * KT * C * 2, lp);
+    else dma16(rsV, (int)(((size_t)(arr & 1) * MC + (size_t)row * L + src_slot * 8) * 2), t * KT * 2, lp);
   };
   auto issue_tile = [&](int t, int stage) {
 #pragma unroll
@@ -319,14 +320,13 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
   // plus one 32-bit per-thread offset per operand, so an issue costs no vector instructions and no address registers.
   const unsigned rsl = (unsigned)(tid >> 3), ssl = (unsigned)((tid & 7) ^ ((tid >> 4) & 7)) * 8u;
   const unsigned koff = (rsl * (unsigned)C + ssl) * 2u, voff = (rsl * (unsigned)L + ssl) * 2u;   // bytes
+  // Issued in the buffer form (dma16, conv_common.h): SGPR resource + that one offset VGPR + the wave-uniform part as an SGPR offset.
+  const __amdgpu_buffer_rsrc_t rsK = dma_resource(kbase), rsV = dma_resource(vbase);
   auto issue_piece = [&](int t, int stage, int j) {
     const int arr = j >> 1, half = j & 1;
-    const char* ub = (arr < 2) ? reinterpret_cast<const char*>(kbase + (size_t)(arr & 1) * MC + (size_t)(t * KT + 32 * half) * C)
-                               : reinterpret_cast<const char*>(vbase + (size_t)(arr & 1) * MC + (size_t)(32 * half) * L + t * KT);
-    const char* gp = ub + ((arr < 2) ? koff : voff);
     __bf16* lp = sm + stage * STAGE + (j * NT + wave * 64) * 8;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                     (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+    if (arr < 2) dma16(rsK, (int)koff, (int)(((size_t)(arr & 1) * MC + (size_t)(t * KT + 32 * half) * C) * 2), lp);
+    else dma16(rsV, (int)voff, (int)(((size_t)(arr & 1) * MC + (size_t)(32 * half) * L + t * KT) * 2), lp);
   };
   auto issue_tile = [&](int t, int stage) {
 #pragma unroll
@@ -589,6 +589,7 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
 int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, int form, hipStream_t stream) {
   PF_REQUIRE(planes && (o || o_planes) && batch > 0 && n_heads > 0 && l > 0 && l % 128 == 0, "attention_bf3: L must be a positive multiple of 128");
   PF_REQUIRE(form == PF_OPT_AUTO || form == 0 || (form == 1 && l % 256 == 0), "attention_bf3: form must be auto, 0 (128-query) or 1 (256-query, L %% 256 == 0)");
+  PF_REQUIRE((size_t)batch * l * n_heads * 64 * 2 * 2 < ((size_t)1 << 31), "attention_bf3: a plane pair must stay below 2 GiB (32-bit offsets of the direct-to-LDS loads)");
   // auto: the 256-query form where it still gives three quarters of the CUs a workgroup
   const bool wide = l % 256 == 0 && (form == PF_OPT_AUTO ? (l / 256) * n_heads * batch >= num_cus() * 3 / 4 : form == 1);
   AttnP3 p{static_cast<const __bf16*>(planes), o, ldo, static_cast<__bf16*>(o_planes), batch, n_heads, l, 0.125f,

@@ -256,15 +256,17 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   // direct global->LDS copy of one weight tile (no registers, no transform): LDS image = tile order, lane-linear
   // per-thread source pointers of the NW pieces inside a tile are fixed; a tile only adds a wave-uniform offset
   static_assert(NT % (2 * BN) == 0, "pieces of a thread must be whole k8 rows apart");
-  const size_t wrow = (size_t)2 * p.Npad * 8;   // bf16 elements per k8 row pair (hi|lo planes)
-  const __bf16* gw0 = static_cast<const __bf16*>(p.w) + ((size_t)((tid / (2 * BN)) * 2 + ((tid / BN) & 1)) * p.Npad + n0 + tid % BN) * 8;
+  // (buffer form, dma16 of conv_common.h: SGPR resource at this column tile's first weight, one offset VGPR per lane, the tile as a
+  // wave-uniform SGPR offset - next to MFMAs it issues several times faster than the global form with its address VGPR pair)
+  const int wrow_b = 2 * p.Npad * 8 * 2;        // BYTES per k8 row pair (hi|lo planes); a layer's packing is a few MB: int offsets
+  const __amdgpu_buffer_rsrc_t rsW = dma_resource(static_cast<const __bf16*>(p.w) + (size_t)n0 * 8);
+  const int vw0 = (((tid / (2 * BN)) * 2 + ((tid / BN) & 1)) * p.Npad + tid % BN) * 16;
   auto gldsW = [&](int chunk, int tap, int buf) {
-    const size_t toff = ((size_t)(q * TAPS + tap) * K8 + (size_t)(cbeg + chunk) * 4) * wrow;   // q != 0 only for the folded conv
+    const int toff = ((q * TAPS + tap) * K8 + (cbeg + chunk) * 4) * wrow_b;   // q != 0 only for the folded conv
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       __bf16* l = sW + buf * (TOTW * 8) + (wave * 64 + j * NT) * 8;   // wave-uniform base; the hardware adds lane*16 B
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw0 + toff + (size_t)j * (NT / (2 * BN)) * wrow),
-                                       (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+      dma16(rsW, vw0, toff + j * (NT / (2 * BN)) * wrow_b, l);
     }
   };
 
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       // Issued as inline asm, hidden from hipcc's wait-count pass: with direct-to-LDS loads in flight the compiler waits
       // vmcnt(0) before the first use of an ordinary load's result, which drained the whole weight ring once per chunk.
       // The destination registers are read by transformSub only after the hand-placed vmcnt wait below.
+      // (the buffer form that pays for the weight tiles was tried here too: no gain at 0.7 halo loads per tap - kept global)
       if (i < NA) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[i]) : "v"(src + co + (unsigned)(max(poff[i], 0) * cs + c4 * 4)));
       else if (PRO == 1 || PRO == 2) {
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vsc) : "v"(p.sc + (size_t)b * cin + cg + c4 * 4));
@@ -446,10 +449,9 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       }
     };
     auto gldsWpiece = [&](int chunk, int tap, int buf, int j) {
-      const size_t toff = ((size_t)(q * TAPS + tap) * K8 + (size_t)(cbeg + chunk) * 4) * wrow;
+      const int toff = ((q * TAPS + tap) * K8 + (cbeg + chunk) * 4) * wrow_b;
       __bf16* l = sW + buf * (TOTW * 8) + (wave * 64 + j * NT) * 8;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw0 + toff + (size_t)j * (NT / (2 * BN)) * wrow),
-                                       (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+      dma16(rsW, vw0, toff + j * (NT / (2 * BN)) * wrow_b, l);
     };
     int rs_cur = 0;                     // DYN: ring slot of the current tap's tile (wave-uniform)
     {

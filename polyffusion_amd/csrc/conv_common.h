@@ -23,6 +23,17 @@ __device__ __forceinline__ bf16x8 lds_read128(unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(LO));
   return __builtin_bit_cast(bf16x8, v);
 }
+// Direct-to-LDS copy of 16 bytes per lane in its BUFFER form: SGPR resource (base) + one 32-bit offset VGPR per lane + a wave-uniform
+// SGPR offset, destination = M0-based LDS address + lane * 16.  Next to MFMAs the global form (a 64-bit address VGPR pair per lane)
+// costs its wave 100-300 cycles to issue at two waves per SIMD, this one 20-110 (tools/micro/glds_issue.hip): every streaming loop of
+// the library issues its tile pieces this way.  `base` must cover [voff + soff, +16) for every lane; offsets are bytes, < 2 GiB.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_resource(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
 template <int N>
 __device__ __forceinline__ void lgkm_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
 template <int I, int N, class F>

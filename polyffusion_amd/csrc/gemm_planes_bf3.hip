@@ -42,33 +42,34 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
   const size_t MK = (size_t)p.B * L * K;
   const __bf16* A = reinterpret_cast<const __bf16*>(p.x0);
 
-  // per-thread source pointers of the stage pieces (a chunk adds a uniform offset)
-  const __bf16* ga[NAu];
+  // per-thread byte offsets of the stage pieces inside the workgroup's A rows / W column tile (a chunk adds a wave-uniform offset):
+  // buffer-form direct-to-LDS loads (dma16, conv_common.h).  The A resource starts at this sample tile's first row of the hi plane,
+  // so every offset stays far below 2 GiB whatever the tensor size.
+  const __bf16* Abase = A + ((size_t)b * L + min(ox0, L - 1)) * K;
+  const __amdgpu_buffer_rsrc_t rsA = dma_resource(Abase), rsW = dma_resource(static_cast<const __bf16*>(p.w) + (size_t)n0 * 8);
+  int va[NAu];
 #pragma unroll
   for (int j = 0; j < NAu; ++j) {
     const int u = tid + j * 256;
     const int plane = u / (BM * 4), w = u % (BM * 4), row = w >> 2, slot = w & 3;
-    const int srow = min(ox0 + row, L - 1);                       // rows past the sample are never stored
-    ga[j] = A + (size_t)plane * MK + ((size_t)b * L + srow) * K + ((slot ^ ((row >> 2) & 3)) * 8);
+    const int srow = min(ox0 + row, L - 1) - min(ox0, L - 1);     // rows past the sample are never stored
+    va[j] = (int)(((size_t)plane * MK + (size_t)srow * K + ((slot ^ ((row >> 2) & 3)) * 8)) * 2);
   }
-  const __bf16* gw[NWu];
+  int vw[NWu];
 #pragma unroll
   for (int j = 0; j < NWu; ++j) {
     const int u = tid + j * 256;
     const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
-    gw[j] = static_cast<const __bf16*>(p.w) + ((size_t)(k8l * 2 + plane) * p.Npad + n0 + n) * 8;
+    vw[j] = (int)((((size_t)(k8l * 2 + plane) * p.Npad + n) * 8) * 2);
   }
-  const size_t wrow = (size_t)2 * p.Npad * 8;
+  const int wrow_b = 2 * p.Npad * 8 * 2;      // bytes per k8 row pair (hi|lo planes)
   auto issue = [&](int chunk, int stage) {
     __bf16* sb = sm + stage * STAGE;
+    const int soa = chunk * BK * 2, sow = chunk * 4 * wrow_b;
 #pragma unroll
-    for (int j = 0; j < NAu; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[j] + chunk * BK),
-                                       (__attribute__((address_space(3))) void*)(sb + (wave * 64 + j * 256) * 8), 16, 0, 0);
+    for (int j = 0; j < NAu; ++j) dma16(rsA, va[j], soa, sb + (wave * 64 + j * 256) * 8);
 #pragma unroll
-    for (int j = 0; j < NWu; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[j] + (size_t)chunk * 4 * wrow),
-                                       (__attribute__((address_space(3))) void*)(sb + AU * 8 + (wave * 64 + j * 256) * 8), 16, 0, 0);
+    for (int j = 0; j < NWu; ++j) dma16(rsW, vw[j], sow, sb + AU * 8 + (wave * 64 + j * 256) * 8);
   };
 
   // LDS byte addresses of this lane's fragments inside a stage.  The swizzled 16-byte slot of K step s is
@@ -187,6 +188,7 @@ static int launch_gp(ConvP& p, hipStream_t stream) {
 
 // a.x0 = A planes (bf16 hi [M][K] then lo [M][K]); everything else as pf_conv2d with ks = 1, prologue 0, bf16x3 weights
 int launch_gemm_planes(const pf_conv_args& a, hipStream_t stream) {
+  PF_REQUIRE((size_t)a.batch * a.win * a.c0 * 2 * 2 < ((size_t)1 << 31), "gemm_planes: the A plane pair must stay below 2 GiB (32-bit offsets of the direct-to-LDS loads)");
   ConvP p;
   memset(&p, 0, sizeof p);
   p.x0 = a.x0; p.c0 = a.c0; p.B = a.batch; p.Hin = 1; p.Win = a.win; p.Hout = 1; p.Wout = a.win;

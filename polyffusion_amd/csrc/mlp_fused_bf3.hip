@@ -60,19 +60,18 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
   // ---- weight stream -------------------------------------------------------------------------------------------------
   // unit u = tid + 256 q of a slot (16 B each).  W1 slot (chunk r of slice j): k8 = 4 r + q, plane = tid / 128, n = 128 j + tid % 128.
   // W2 slot (16-deep step c of slice j): k8 = 8 j + 2 c + (q >> 1), plane = q & 1, n = tid.
-  const __bf16* g1 = e.w1 + ((size_t)(tid >> 7) * 2048 + (tid & 127)) * 8;
-  const __bf16* g2 = static_cast<const __bf16*>(p.w) + (size_t)tid * 8;
+  // (buffer-form direct-to-LDS loads, dma16 of conv_common.h: one SGPR resource per matrix, one offset VGPR per lane, the slot as a
+  // wave-uniform SGPR offset)
+  const __amdgpu_buffer_rsrc_t g1 = dma_resource(e.w1), g2 = dma_resource(p.w), g3 = dma_resource(TAIL ? static_cast<const void*>(e.w3) : p.w);
+  const int v1 = (int)(((tid >> 7) * 2048 + (tid & 127)) * 16), vn = tid * 16;
   // one 1 KiB piece (q = 0..3) of a slot into ring position pos
   auto issue_w1 = [&](int js, int c, int pos, int q) {   // chunk c (32 k) of ff1 slice js
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g1 + ((size_t)((c * 4 + q) * 2) * 2048 + js * 128) * 8),
-                                     (__attribute__((address_space(3))) void*)(sR + pos * SLOT_B + wave * 1024 + q * 4096), 16, 0, 0);
+    dma16(g1, v1, (((c * 4 + q) * 2) * 2048 + js * 128) * 16, sR + pos * SLOT_B + wave * 1024 + q * 4096);
   };
-  auto issue_wn = [&](const __bf16* gbase, int kstep, int pos, int q) {   // 16-deep step `kstep` of a [K][256] matrix
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + (size_t)(((kstep * 2 + (q >> 1)) * 2 + (q & 1)) * 256) * 8),
-                                     (__attribute__((address_space(3))) void*)(sR + pos * SLOT_B + wave * 1024 + q * 4096), 16, 0, 0);
+  auto issue_wn = [&](const __amdgpu_buffer_rsrc_t& gbase, int kstep, int pos, int q) {   // 16-deep step `kstep` of a [K][256] matrix
+    dma16(gbase, vn, (((kstep * 2 + (q >> 1)) * 2 + (q & 1)) * 256) * 16, sR + pos * SLOT_B + wave * 1024 + q * 4096);
   };
   auto issue_w2 = [&](int js, int c, int pos, int q) { issue_wn(g2, js * 4 + c, pos, q); };   // 16-deep step c of ff2 slice js
-  const __bf16* g3 = TAIL ? e.w3 + (size_t)tid * 8 : g2;
   // Slot order of the whole kernel (the GeGLU of slice j runs inside the MFMA gaps of ff1 slice j+1, so ff2 lags one slice):
   //   P0..P7 = ff1 slice 0 | for j = 0..14: M(j,0..7) = ff1 slice j+1, M(j,8..11) = ff2 slice j | F0..F3 = ff2 slice 15
   // every group is a multiple of RING slots, so a slot's ring position is its index within the group mod RING.
