@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-4 profile collection (same passes as tools/run_profiles.sh, one timed window): tools/run_profiles_r04.sh [tag]
-# (r04a = after hoisting the step-invariant prefix / in-kernel noise, r04b = end of the round)
+# (r04a = after hoisting the step-invariant prefix / in-kernel noise, r04b = before, r04c = after the buffer-form direct-to-LDS loads)
 tag=${1:-r04a}
 tools/run_profiles.sh $tag
 python tools/prof_summary.py $(find gpurun_out/prof_$tag/trace -name "*.db" | head -1) 12 > gpurun_out/prof_$tag/kernel_trace.md
