@@ -104,8 +104,10 @@ int pf_unet_n_launches_prepared(const pf_unet* u, int batch, int n_cond, int has
  *                       GEMM + proj_out (bit-identical results); auto: fused when its last round of workgroups is >= 85 % full
  *   PF_OPT_ATTN_WIDE  - self-attention with 256-query vs 128-query workgroups (equal up to summation order); auto: 256 when L % 256 == 0
  *                       and that still gives 3/4 of the CUs a workgroup
- *   PF_OPT_CONV_T16   - 16x16-pixel tile for the 64-output-channel 3x3 convs with >= 128 input channels vs the 8x16 tile */
-enum { PF_OPT_MLP_FUSED = 0, PF_OPT_ATTN_WIDE = 1, PF_OPT_CONV_T16 = 2, PF_OPT_COUNT = 3 };
+ *   PF_OPT_CONV_T16   - 16x16-pixel tile for the 64-output-channel 3x3 convs with >= 128 input channels vs the 8x16 tile
+ *   PF_OPT_CONV_PP    - 3x3 convs whose 128-wide tiles give every CU at most one workgroup (B = 16: the 32x32 level) as 8-wave workgroups:
+ *                       two wave groups split K and run half a tap apart, one loading while the other computes (equal up to summation order) */
+enum { PF_OPT_MLP_FUSED = 0, PF_OPT_ATTN_WIDE = 1, PF_OPT_CONV_T16 = 2, PF_OPT_CONV_PP = 3, PF_OPT_COUNT = 4 };
 enum { PF_OPT_AUTO = -1, PF_OPT_OFF = 0, PF_OPT_ON = 1 };
 int pf_unet_set_option(pf_unet* u, int option, int value);
 int pf_unet_get_option(const pf_unet* u, int option);
@@ -308,6 +310,7 @@ typedef struct pf_conv_args {
    * device-resident t[b]); rows outside [0, sbias_nrows) are clamped */
   const int64_t* sbias_rows; int32_t sbias_nrows;
   int32_t no_t16;          /* != 0: never pick the 16x16-pixel tile (PF_OPT_CONV_T16 = off) */
+  int32_t no_pp;           /* != 0: never run the two-group ping-pong form of the 128-wide tile (PF_OPT_CONV_PP = off) */
 } pf_conv_args;
 /* scratch bytes a launch with these arguments would like for split-K (0 = the launch does not split) */
 size_t pf_conv_splitk_ws_bytes(const pf_conv_args* a);

@@ -40,7 +40,7 @@ class UNetPrepared(C.Structure):
     _fields_ = [("time_table", C.c_void_p), ("n_time_rows", C.c_int32), ("cross_bias", C.c_void_p)]
 
 
-OPT_MLP_FUSED, OPT_ATTN_WIDE, OPT_CONV_T16 = 0, 1, 2
+OPT_MLP_FUSED, OPT_ATTN_WIDE, OPT_CONV_T16, OPT_CONV_PP = 0, 1, 2, 3
 OPT_AUTO, OPT_OFF, OPT_ON = -1, 0, 1
 
 
@@ -64,7 +64,7 @@ class ConvArgs(C.Structure):
         ("skip_w", C.c_void_p), ("skip_bias", C.c_void_p),
         ("gn_stats0", C.c_void_p), ("gn_tiles0", C.c_int32), ("gn_stats1", C.c_void_p), ("gn_tiles1", C.c_int32),
         ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float), ("gn_groups", C.c_int32),
-        ("sbias_rows", C.c_void_p), ("sbias_nrows", C.c_int32), ("no_t16", C.c_int32),
+        ("sbias_rows", C.c_void_p), ("sbias_nrows", C.c_int32), ("no_t16", C.c_int32), ("no_pp", C.c_int32),
     ]
 
 

@@ -58,14 +58,16 @@ constexpr int conv_bf3_row_pitch() {
 #ifndef PF_KG2_RING
 #define PF_KG2_RING 5
 #endif
-template <int KS, int KG>
-constexpr int conv_bf3_wring() { return KS == 3 ? (KG == 2 ? PF_KG2_RING : 3) : 2; }
+template <int KS, int BN, int KG>
+constexpr bool conv_bf3_pingpong() { return KS == 3 && BN == 128 && KG == 2; }
+template <int KS, int KG, int BN = 64>
+constexpr int conv_bf3_wring() { return KS == 3 ? (KG == 2 && !conv_bf3_pingpong<KS, BN, KG>() ? PF_KG2_RING : 3) : 2; }
 
 // LDS bytes of one wave group: the main loop's halo image + weight ring, or the fused 1x1 phase's double buffers
 template <int KS, int STRIDE, int TH, int TW, int BN, bool SKIP, int KG = 1>
 constexpr size_t conv_bf3_group_lds() {
   constexpr int THIN = (TH - 1) * STRIDE + KS, TWIN = (TW - 1) * STRIDE + KS;
-  constexpr int NABUF = (KS == 1) ? 2 : 1, WRING = conv_bf3_wring<KS, KG>();
+  constexpr int NABUF = (KS == 1) ? 2 : 1, WRING = conv_bf3_wring<KS, KG, BN>();
   constexpr size_t main_b = (size_t)(2 * NABUF * THIN * conv_bf3_row_pitch<KS, STRIDE, TWIN, BN>() + WRING * 8 * BN * 8) * 2;
   constexpr int NB1 = BN >= 128 ? 2 : 1;   // buffers of the fused 1x1 phase (see conv_bf3_kernel: the 64-wide tile keeps its third workgroup per CU)
   constexpr size_t skip_b = SKIP ? (size_t)(2 * NB1 * TH * TW * 40 + NB1 * 8 * BN * 8) * 2 : 0;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   constexpr int NW = TOTW / NT;
   constexpr int TAPS = KS * KS;
   constexpr int NABUF = (KS == 1) ? 2 : 1;
-  constexpr int WRING = conv_bf3_wring<KS, KG>();   // W tile buffers (3x3: direct-to-LDS ring of 3, deeper for KG == 2; the 4-tap folded conv: ring of 2)
+  constexpr int WRING = conv_bf3_wring<KS, KG, BN>();   // W tile buffers (3x3: direct-to-LDS ring of 3, deeper for KG == 2; the 4-tap folded conv: ring of 2)
   constexpr int WM = BM / NWM, WN = BN / 2;
   constexpr int FM = WM / 32, FN = WN / 32;
   constexpr int PAD = (KS == 3) ? 1 : 0;   // KS == 2 (parity-folded upsampling conv): the pad depends on the parity, see iy0
@@ -364,8 +366,10 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     // offsets live in SGPRs (rs_cur / rs_nxt, advanced once per tap) and are added to the weight base register (one VALU op per tap)
     constexpr bool DYN = TAPS % WRING != 0;
     constexpr int NAL = NA + (PRO != 0 ? 2 : 0);   // vector loads issued by loadA (all unconditional)
+    // PP: the two wave groups of a KG = 2 workgroup run half a tap apart (see the PP loop below); its first segment issues tile 2
+    constexpr bool PP = conv_bf3_pingpong<KS, BN, KG>();
 #pragma unroll
-    for (int d = 0; d < WRING; ++d) gldsW(0, d, d);
+    for (int d = 0; d < (PP ? 2 : WRING); ++d) gldsW(0, d, d);
     TR();
     loadA(0);
     TR();
@@ -453,6 +457,105 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       __bf16* l = sW + buf * (TOTW * 8) + (wave * 64 + j * NT) * 8;
       dma16(rsW, vw0, toff + j * (NT / (2 * BN)) * wrow_b, l);
     };
+    if constexpr (PP) {
+      // ---- ping-pong form (KG == 2, 128-wide tile): a tap is a LOAD segment - every fragment of the tap (both K steps) into registers,
+      // the refill of the ring slot freed one tap ago, the next chunk's halo loads - and a COMPUTE segment - the tap's 6G MFMAs back to
+      // back, the halo arithmetic and (tap 8) the halo image rewrite as fillers - each closed by the workgroup barrier.  Group 1 enters
+      // the loop one barrier late, so on every SIMD one wave computes while its partner loads: the matrix pipe sees an MFMA stream
+      // that no fragment wait interrupts (tools/micro/tap_pingpong.hip: 100 % of the pipe on this mix, against 88-92 % dealt out between
+      // the MFMAs of a single stream).  A group's barriers are those of the lockstep form (all reads of a slot before its refill, all
+      // pieces of a tile landed before its first read); pairing them with the other group's barriers of the other kind changes nothing.
+      static_assert(WRING == 3 && TAPS == 9 && NS == 2, "ping-pong loop: ring of 3 over 9 taps");
+      bf16x8 ah2[NS][FM], al2[NS][FM], bh2[NS][FN], bl2[NS][FN];
+      int woff[NA];   // element offsets of this thread's halo pieces (fixed: the rewrite in tap 8 must not need VALU work)
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int pix = min(tid / KQ + i * PSTEP, NPIX - 1);
+        woff[i] = (pix / TWIN) * RP + (pix % TWIN) * PITCH + c4 * 4;
+      }
+      if (kg) __builtin_amdgcn_s_barrier();
+      for (int chunk = 0; chunk < nchunk; ++chunk) {
+        const bool has_next = chunk + 1 < nchunk;
+        const int chunkn = min(chunk + 1, nchunk - 1);
+        static_for<0, TAPS>([&](auto tapc) {
+          constexpr int tap = decltype(tapc)::value;
+          constexpr int aoff = (tap / KS) * RP + (tap % KS) * PITCH;
+          constexpr int slot_cur = tap % WRING, slot_ref = (tap + 2) % WRING;
+          constexpr int T0 = 2, TSPAN = TAPS - 1 - T0;
+          int c2 = chunk + (tap + 2) / TAPS, t2 = (tap + 2) % TAPS;     // the tile issued by this tap: two taps ahead
+          if (c2 >= nchunk) { c2 = nchunk - 1; t2 = TAPS - 1; }
+          // ---- LOAD: fragment reads first (their latency covers everything else), then the copies, then this tap's halo work.
+          // VALU work belongs HERE: a computing wave queues its MFMAs and runs ahead to the closing barrier - that is what lets the
+          // partner queue its own MFMAs before the pipe runs dry - and any VALU instruction between or after the MFMAs would hold
+          // the wave back until the queue has drained (in-order VALU): measured +190 cycles per segment with the fillers there.
+          TR();
+          SB();
+          static_for<0, NS>([&](auto sc_) {
+            constexpr int st = decltype(sc_)::value;
+            static_for<0, FM>([&](auto i) { al2[st][i.value] = lds_read128<ALO + (aoff + st * 16) * 2>(abase[i.value]); });
+            static_for<0, FN>([&](auto i) { bh2[st][i.value] = lds_read128<slot_cur * WSLOT + ((4 * st) * BN + i.value * 32) * 16>(wb); });
+            static_for<0, FM>([&](auto i) { ah2[st][i.value] = lds_read128<(aoff + st * 16) * 2>(abase[i.value]); });
+            static_for<0, FN>([&](auto i) { bl2[st][i.value] = lds_read128<slot_cur * WSLOT + ((4 * st + 1) * BN + i.value * 32) * 16>(wb); });
+          });
+          static_for<0, NW>([&](auto jc) { gldsWpiece(c2, t2, slot_ref, decltype(jc)::value); });
+          if constexpr (tap == 0) {
+            static_for<0, NA + 1>([&](auto ic) { if (ic.value < NA || PRO != 0) loadApiece(chunkn, ic.value); });
+          }
+          if constexpr (tap == T0) {   // first use of the halo registers: their loads (tap 0) are older than the two tiles issued since
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NW) : "memory");
+            SB();
+          }
+          if (has_next) {
+            static_for<0, NA>([&](auto ic) {
+              constexpr int i = decltype(ic)::value;
+              if constexpr (tap == T0 + (i * TSPAN) / NA) { static_for<0, 4>([&](auto sc_) { transformSub(i, decltype(sc_)::value); }); }
+            });
+          }
+          SB();
+          TR();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          TR();
+          __builtin_amdgcn_s_barrier();
+          FENCE();
+          SB();
+          TR();
+          // ---- COMPUTE: MFMAs only (tap 8: plus the LDS stores of the next halo image - every wave holds its tap-8 fragments)
+          static_for<0, NS>([&](auto sc_) {
+            constexpr int st = decltype(sc_)::value;
+            static_for<0, FM>([&](auto fm) { static_for<0, FN>([&](auto fn) {
+              acc[fm.value][fn.value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al2[st][fm.value], bh2[st][fn.value], acc[fm.value][fn.value], 0, 0, 0);
+              SB(); }); });
+            static_for<0, FN>([&](auto fn) { static_for<0, FM>([&](auto fm) {
+              acc[fm.value][fn.value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah2[st][fm.value], bh2[st][fn.value], acc[fm.value][fn.value], 0, 0, 0);
+              SB(); }); });
+            static_for<0, FM>([&](auto fm) { static_for<0, FN>([&](auto fn) {
+              acc[fm.value][fn.value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah2[st][fm.value], bl2[st][fn.value], acc[fm.value][fn.value], 0, 0, 0);
+              SB(); }); });
+          });
+          if constexpr (tap == TAPS - 1) {
+            if (has_next) {
+#pragma unroll
+              for (int i = 0; i < NA; ++i) {
+                if (tid / KQ + i * PSTEP < NPIX) {
+                  *reinterpret_cast<bf16x4*>(sAh + woff[i]) = qh[i];
+                  *reinterpret_cast<bf16x4*>(sAl + woff[i]) = ql[i];
+                }
+              }
+            }
+          }
+          SB();
+          TR();
+          // the next tap's tile has landed (newer: the tile issued by this tap and, until tap 2 has consumed them, the halo loads);
+          // lgkmcnt(0): the halo image rewrite of tap 8
+          asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NW + (tap < T0 ? NAL : 0)) : "memory");
+          TR();
+          __builtin_amdgcn_s_barrier();
+          FENCE();
+          SB();
+        });
+      }
+      if (!kg) __builtin_amdgcn_s_barrier();
+    } else {
     int rs_cur = 0;                     // DYN: ring slot of the current tap's tile (wave-uniform)
     {
       constexpr int slot_cur = 0;
@@ -578,6 +681,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
         rs_cur = rs_nxt;
       });
     }
+    }
 #undef LD_AL1
 #undef LD_AH1
 #undef LD_BH1
@@ -597,10 +701,12 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     // and to the compiler those values are dead - it used their registers for the accumulator copies of the loop-exit edge, i.e.
     // BEFORE the wait above, and a late LDS return then overwrote an accumulator (seen as run-to-run differences once a change
     // elsewhere altered the register assignment).  A use after the wait keeps the registers allocated until the data has landed.
+    if constexpr (!PP) {   // (the ping-pong form leaves no fragment read in flight)
     #pragma unroll
     for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(al[i]), "v"(ah[i]));
     #pragma unroll
     for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(bh[i]), "v"(bl[i]));
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -811,6 +917,10 @@ static int dispatch_tile3(ConvP& p, int tile, hipStream_t s) {
       // (the 128x128 tile split the same way measured neutral - its two wave groups run in lockstep behind the shared barrier - DESIGN.md 3)
       const bool kg2 = tile == 2 && p.ksplit == 1 && blocks <= 256 && ((p.c0 + p.c1) / 32) % 2 == 0 && (!p.sw || ((p.sc0 + p.sc1) / 32) % 2 == 0);
       if (kg2) return p.sw ? launch3_cfg<3, 1, false, 4, 16, 64, 1, 2, true, 2>(p, s) : launch3_cfg<3, 1, false, 4, 16, 64, 1, 2, false, 2>(p, s);
+      // ... but run as two groups half a tap apart (conv_bf3_pingpong) it gains: one group's fragment reads / copies / halo arithmetic
+      // hide behind the other's MFMAs (B = 16: the 32x32 level; B = 8: the 64x64 level)
+      if (p.pp && tile == 0 && p.ksplit == 1 && blocks <= 256 && ((p.c0 + p.c1) / 32) % 2 == 0 && (!p.sw || ((p.sc0 + p.sc1) / 32) % 2 == 0))
+        return p.sw ? launch3_cfg<3, 1, false, 8, 16, 128, 1, 2, true, 2>(p, s) : launch3_cfg<3, 1, false, 8, 16, 128, 1, 2, false, 2>(p, s);
       if (tile == 3) return p.sw ? launch3_cfg<3, 1, false, 16, 16, 64, 1, 2, true>(p, s) : launch3_cfg<3, 1, false, 16, 16, 64, 1, 2, false>(p, s);
       if (p.sw) {   // fused skip projection: only the ResBlock second-conv configurations are instantiated
         if (tile == 0) return launch3_cfg<3, 1, false, 8, 16, 128, 1, 2, true>(p, s);
@@ -839,6 +949,7 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   p.sb_rows = reinterpret_cast<const long long*>(a.sbias_rows); p.sb_nrows = a.sbias_nrows;
   p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out;
   p.ksplit = conv_ksplit(a);
+  p.pp = !a.no_pp;
   p.partial = p.ksplit > 1 ? static_cast<float*>(a.splitk_ws) : nullptr;
   p.qkv = a.qkv_planes; p.out_planes = a.out_planes;
   if (a.gn_stats0 && (a.prologue == 1 || a.prologue == 2)) {

@@ -72,6 +72,7 @@ struct ConvP {
   const void* sw; const float* bias2;
   void* out_planes;             // result as bf16 hi/lo planes [M][ld_out] | [M][ld_out] instead of fp32 (consumer: gemm_planes_bf3.hip)
   void* qkv;                    // fused q|k|v projection written as bf16 hi/lo planes for attention_bf3.hip (d_head 64)
+  int pp;                       // host side only: the two-group ping-pong form is allowed (pf_conv_args.no_pp)
   int ksplit; float* partial;   // split-K: raw accumulators to partial[split][M][N]; bias/residual/statistics happen in the reduce kernel
   // GroupNorm finalize inside the consumer (bf16x3 kernels): per-tile statistics of the one or two producers, see gn_fused_prologue
   const float* gn_s0; const float* gn_s1; int gn_t0, gn_t1;

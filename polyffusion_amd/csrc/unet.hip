@@ -68,7 +68,7 @@ struct pf_unet {
   int cross_cursor = 0;
   size_t cross_o_cursor = 0;
   const float* wdev = nullptr;
-  int opt[PF_OPT_COUNT] = {PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO};   // pf_unet_set_option
+  int opt[PF_OPT_COUNT] = {PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO};   // pf_unet_set_option
   // profiling
   int precision = PF_PREC_F32;
   bool profiling = false;
@@ -414,6 +414,7 @@ struct Ctx {
     const bool bf3 = u->precision == PF_PREC_BF16X3 && cin_ % 32 == 0;
     if (bf3) a.precision = PF_PREC_BF16X3;   // decided before the tile (and thus the statistics layout) is chosen
     a.no_t16 = u->opt[PF_OPT_CONV_T16] == PF_OPT_OFF;
+    a.no_pp = u->opt[PF_OPT_CONV_PP] == PF_OPT_OFF;
     if (const size_t wsb = conv_splitk_ws_bytes(a)) {   // small-M layer: K-split partial sums live in the temp region
       float* ws = talloc(wsb / 4);
       a.splitk_ws = dry ? (void*)1 : (void*)ws; a.splitk_ws_bytes = wsb;

@@ -224,8 +224,12 @@ def test_plan_options_fused_mlp_and_attention_forms(chd8bar):
         u.set_option("attn_wide", None)
         u.set_option("conv_t16", False)
         assert (u(x, t, c) - base).abs().max().item() <= 1e-4
+        u.set_option("conv_t16", None)
+        u.set_option("conv_pp", False)             # the 32x32-level convs as 4-wave workgroups (one K range) instead of the two-group form
+        assert u.get_option("conv_pp") is False and u.n_launches(B) == n_auto
+        assert (u(x, t, c) - base).abs().max().item() <= 1e-4
     finally:
-        for o in ("mlp_fused", "attn_wide", "conv_t16"):
+        for o in ("mlp_fused", "attn_wide", "conv_t16", "conv_pp"):
             u.set_option(o, None)
     assert torch.equal(u(x, t, c), base)
 
@@ -270,6 +274,50 @@ def test_conv_16x16_pixel_tile_vs_torch(lib, c0, c1):
     kw2 = dict(kw, sbias=dev(table), sbias_rows=rows, sbias_nrows=2 * B)
     run_conv(lib, out=out_r, **kw2)
     assert torch.equal(out_r, out)
+
+
+# ---------------------------------------------------------------------------------------------- two-group ping-pong form, op level
+@pytest.mark.parametrize("c0,c1,skip", [(256, 0, 0), (256, 256, 0), (256, 128, 384)])
+def test_conv_pingpong_form_vs_torch(lib, c0, c1, skip):
+    """(B, H, W) = (16, 32, 32), 256 output channels: 256 tiles of 8x16 pixels x 128 channels, the shape that runs as 8-wave workgroups
+    whose two wave groups split K and work half a tap apart (PF_OPT_CONV_PP) - against F.conv2d (+ the fused 1x1 skip projection of
+    the ResBlock input), against the single-group form (no_pp), and twice for bit-reproducibility."""
+    B, H, W, cout = 16, 32, 32, 256
+    cin = c0 + c1
+    x = rnd((B, cin, H, W), 31) * 1.5 + 0.3
+    w, bias = rnd((cout, cin, 3, 3), 32, (1.0 / (cin * 9)) ** 0.5), rnd((cout,), 33, 0.1)
+    gamma, beta = 1 + 0.1 * rnd((cin,), 34), 0.1 * rnd((cin,), 35)
+    sb = rnd((B, cout), 36)
+    ref = F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-5)), w, bias, padding=1) + sb[:, :, None, None]
+    x0 = dev(nhwc(x[:, :c0]))
+    x1 = dev(nhwc(x[:, c0:])) if c1 else None
+    sc, sh = gn_scale_shift(lib, x0, x1, dev(gamma), dev(beta), 1e-5)
+    kw = dict(x0=x0, c0=c0, x1=x1, c1=c1, batch=B, hin=H, win=W, ks=3, stride=1, ups=0, w=pack3(lib, w), n=cout, prologue=1, sc=sc, sh=sh,
+              bias=dev(bias), sbias=dev(sb), ld_sbias=cout, ld_out=cout, precision=1)
+    if skip:
+        xs = rnd((B, skip, H, W), 37)
+        ws, bs = rnd((cout, skip, 1, 1), 38, (1.0 / skip) ** 0.5), rnd((cout,), 39, 0.1)
+        ref = ref + F.conv2d(xs, ws, bs)
+        kw.update(skip_x0=dev(nhwc(xs)), skip_c0=skip, skip_w=pack3(lib, ws), skip_bias=dev(bs))
+    else:
+        res = rnd((B, cout, H, W), 40)
+        ref = ref + res
+        kw.update(res=dev(nhwc(res)), ld_res=cout)
+    out = torch.empty(B, H, W, cout, device="cuda")
+    stats = torch.zeros(B, (H // 8) * (W // 16), cout, 2, device="cuda")
+    run_conv(lib, out=out, stats_out=stats, **kw)
+    o = out.cpu()
+    assert (o - nhwc(ref)).abs().max().item() < 3e-4
+    tot = stats.cpu().double().sum(1)
+    od = o.double()
+    assert (tot[..., 0] - od.sum((1, 2))).abs().max() < 5e-2 and (tot[..., 1] - (od * od).sum((1, 2))).abs().max() < 5e-1
+    out1 = torch.empty_like(out)
+    run_conv(lib, out=out1, no_pp=1, **kw)
+    d = (out1 - out).abs().max().item()
+    assert 0 < d < 2e-5                              # the two forms differ (K summed in two halves), in the last bits only
+    out2 = torch.empty_like(out)
+    run_conv(lib, out=out2, **kw)
+    assert torch.equal(out2, out)
 
 
 # ---------------------------------------------------------------------------------------------- all samples vs the oracle
