@@ -29,6 +29,7 @@ Extra objects (see DESIGN.md "Measurement"):
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -125,6 +126,33 @@ def cpu_baseline(params, reps=3):
                       f"after a warm-up step on the same inputs; {best} torch threads (best of the sweep) of {ncpu} host CPUs",
             "step_seconds": [round(t, 3) for t in times],
             "thread_sweep_steps_per_s": {str(n): round(1.0 / t, 4) for n, t in probes.items()}}
+
+
+def mfma_sustained(launches: int = 10, iters: int = 4000) -> dict:
+    """What the bf16 matrix pipe sustains on THIS box at 100 % duty on operands with random signs / mantissas (pf_mfma_probe: 8 waves
+    per CU, dependency-free MFMA streams).  The part is power-managed - such a stream clocks ~1.6 GHz where the nominal peak assumes
+    2.4 - so this, not the nominal 2.5 PFLOP/s, is what a perfect main loop could reach here.  Median of the later launches (the first
+    ones run before the power management has settled)."""
+    lib = _lib.load()
+    sink = torch.zeros(1, device="cuda")
+    fl = C.c_double(0.0)
+    evs = []
+    for _ in range(launches):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.pf_mfma_probe(sink.data_ptr(), iters, C.byref(fl), _lib.current_stream()), "pf_mfma_probe")
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ms = [a.elapsed_time(b) for a, b in evs]
+    tf = sorted(fl.value / (m * 1e-3) / 1e12 for m in ms[launches // 2:])
+    med = tf[len(tf) // 2]
+    return {"tflops": round(med, 1), "unit": "TFLOP/s raw bf16 (bf16x3 products: / 3)", "frac_of_nominal": round(med / PEAK_BF16_MFMA_TFLOPS, 4),
+            "launch_ms": [round(m, 3) for m in ms],
+            "how": "pf_mfma_probe: one 8-wave workgroup per CU, every wave a dependency-free v_mfma_f32_32x32x16_bf16 stream (100 % pipe duty) "
+                   "on operands with random signs and mantissas; median rate of the later launches.  The nominal peak is never reached on "
+                   "real data: the part clocks to its power budget.  (Register operands only: a loop that also streams its operands through the LDS "
+                   "sustains less - tools/micro/tap_pingpong.hip: 1.65 PFLOP/s)"}
 
 
 class ClockProbe:
@@ -462,6 +490,12 @@ def main():
                                               "brackets (median of empty pairs: event_pair_overhead_ms); achieved/frac use the raw durations and are "
                                               "therefore a lower bound, *_event_corrected subtract one pair per launch and are an upper bound - "
                                               "rocprofv3's per-kernel averages (profiles/) lie between the two"}
+            if args.precision == "bf16x3":
+                sus = mfma_sustained()
+                rl = out["roofline"]
+                rl["sustained"] = sus
+                rl["frac_of_sustained"] = round(ach / (sus["tflops"] / 3.0), 4)
+                rl["frac_of_sustained_event_corrected"] = round(ach_corr / (sus["tflops"] / 3.0), 4)
         out["kernel_ms_per_step"] = {KIND_NAMES[kind]: round(v[1] / args.profile_steps, 4) for kind, v in sorted(agg.items())}
         # the same with one empty event pair taken off every launch: what rocprofv3's per-kernel durations add up to (profiles/)
         out["kernel_ms_per_step_corrected"] = {KIND_NAMES[kind]: round(max(v[1] - v[0] * ev_pair_ms, 0.0) / args.profile_steps, 4)

@@ -164,6 +164,11 @@ int pf_ddim_step_rng(const float* x, const float* eps, const float* orig, const 
  * row x of out[8][2] for every XCD x (XCDs have counters and clocks of their own; rows of XCDs the part does not have stay
  * untouched); two probes around a stretch of stream work give the average shader clock each XCD sustained over it. */
 int pf_clock_probe(uint64_t* out8x2, void* stream);
+/* Measurement aid (bench.py): one launch that keeps the bf16 matrix pipe of every CU 100 % busy (8 waves per CU, dependency-free
+ * v_mfma_f32_32x32x16_bf16 streams on operands with random signs / mantissas) for `iters` x 24 MFMAs per wave; *flops_out = the launch's
+ * flops.  Timed with events it gives the rate the pipe SUSTAINS on this box under its power management - the reference
+ * `roofline.sustained` of the bench line; `sink` is one float of device memory (never written in practice). */
+int pf_mfma_probe(float* sink, int iters, double* flops_out, void* stream);
 
 /* ---- replayable reverse step: everything that changes from one step to the next - the table row, the
  * time-step value fed to the denoiser, the noise draw counter - lives in a small device-resident state, so ONE captured

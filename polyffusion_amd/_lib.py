@@ -105,6 +105,7 @@ SIGNATURES = {
     "pf_ddpm_step_rng_dev": (C.c_int, [C.c_void_p] * 6 + [C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_ddim_step_rng_dev": (C.c_int, [C.c_void_p] * 7 + [C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_clock_probe": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pf_mfma_probe": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
     "pf_step_state_set": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
     "pf_step_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pf_step_end": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

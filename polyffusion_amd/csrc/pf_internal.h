@@ -117,6 +117,7 @@ int launch_ddim_step_rng(const float* x, const float* eps, const float* orig, co
                          const pf_ddim_coef* c_host, const pf_ddim_coef* table, const pf_step_state* st, uint64_t seed, uint64_t draw,
                          uint64_t off, float* out, size_t n, hipStream_t s);
 int launch_clock_probe(unsigned long long* out2, hipStream_t s);
+int launch_mfma_probe(float* sink, int iters, double* flops, hipStream_t s);
 int launch_step_state_set(pf_step_state* st, int64_t index, uint64_t draws, hipStream_t s);
 int launch_step_begin(const pf_step_state* st, const int* time_steps, int64_t* t_out, int batch, hipStream_t s);
 int launch_step_end(pf_step_state* st, int draws_used, hipStream_t s);

@@ -719,6 +719,47 @@ int launch_clock_probe(unsigned long long* out2, hipStream_t s) {
   return PF_OK;
 }
 
+// ------------------------------------------------------------------ matrix-pipe probe
+// What the bf16 matrix pipe SUSTAINS on this box, as a reference for roofline fractions: one 8-wave workgroup per CU (two waves per SIMD),
+// every wave a dependency-free stream of v_mfma_f32_32x32x16_bf16 over four accumulators - 100 % pipe duty - on operands with random signs
+// and mantissas.  The part is power-managed: with such operands a full pipe clocks ~1.6 GHz (all-ones operands: ~2.3 GHz), so the
+// sustained rate sits well below the nominal 2.5 PFLOP/s (tools/micro/tap_pingpong.hip, profiles/r04_ab_pingpong.md).
+// bench.py times a few launches with events; flops per launch = grid x 8 waves x 24 x 32768 x iters.
+__global__ __launch_bounds__(512) void mfma_probe_kernel(float* sink, int iters) {
+  typedef float f32x16_t __attribute__((ext_vector_type(16)));
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  f32x16_t acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  unsigned h = (threadIdx.x + 1) * 2654435761u + blockIdx.x * 40503u;
+  auto nx = [&]() { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return (h & 0x807f807fu) | 0x3f003f00u; };   // bf16 pairs in +-[0.5, 1)
+  bf16x8_t a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u32x4_t ua = {nx(), nx(), nx(), nx()}, ub = {nx(), nx(), nx(), nx()};
+    a[i] = __builtin_bit_cast(bf16x8_t, ua); b[i] = __builtin_bit_cast(bf16x8_t, ub);
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 24; ++i) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i >> 2) & 3], b[(i + (i >> 3)) & 3], acc[i & 3], 0, 0, 0);
+  }
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r += acc[i][0] + acc[i][7];
+  if (r == 12345.678f) sink[0] = r;   // keeps the stream alive; never true in practice
+}
+int launch_mfma_probe(float* sink, int iters, double* flops, hipStream_t s) {
+  PF_REQUIRE(sink && iters > 0 && iters <= (1 << 20), "mfma_probe: bad arguments");
+  const int grid = num_cus();
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(grid), dim3(512), 0, s, sink, iters);
+  PF_CHECK_HIP(hipGetLastError());
+  if (flops) *flops = (double)grid * 8.0 * 24.0 * 32768.0 * iters;
+  return PF_OK;
+}
+
 // ------------------------------------------------------------------ GRU cell update (torch gate order r, z, n)
 // gi = W_ih x_t + b_ih  [B][3H] (row stride ld_gi), gh = W_hh h + b_hh [B][3H]
 __global__ void gru_gates_kernel(const float* __restrict__ gi, int ld_gi, const float* __restrict__ gh, float* __restrict__ h,

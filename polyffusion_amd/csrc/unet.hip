@@ -1094,6 +1094,7 @@ int pf_ddim_step_rng_dev(const float* x, const float* eps, const float* orig, co
   PF_REQUIRE(table && st, "pf_ddim_step_rng_dev: null table / state");
   return launch_ddim_step_rng(x, eps, orig, orig_noise, mask, nullptr, table, st, seed, 0, elem_offset, x_out, n, (hipStream_t)stream);
 }
+int pf_mfma_probe(float* sink, int iters, double* flops_out, void* stream) { return launch_mfma_probe(sink, iters, flops_out, (hipStream_t)stream); }
 int pf_clock_probe(uint64_t* out2, void* stream) { return launch_clock_probe(reinterpret_cast<unsigned long long*>(out2), (hipStream_t)stream); }
 int pf_step_state_set(pf_step_state* st, int64_t index, uint64_t draws, void* stream) { return launch_step_state_set(st, index, draws, (hipStream_t)stream); }
 int pf_step_begin(const pf_step_state* st, const int32_t* time_steps, int64_t* t_out, int batch, void* stream) {

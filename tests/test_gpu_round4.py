@@ -367,3 +367,16 @@ def test_config3_cfg5_batch32_first_middle_last_vs_oracle(chd8bar):
     err = (got[sub].cpu() - xr).abs().max().item()
     print("config 3 (B=32, CFG 5, one DDIM step) max-abs-diff vs oracle on samples 0/15/16/31:", err)
     assert err < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------- measurement aids
+def test_mfma_probe_runs_and_reports_its_flops(lib):
+    """pf_mfma_probe (bench.py's `roofline.sustained`): one launch, the flop count it reports, the sink untouched, bad arguments refused."""
+    sink = torch.zeros(1, device="cuda")
+    fl = C.c_double(0.0)
+    _lib.check(lib.pf_mfma_probe(sink.data_ptr(), 50, C.byref(fl), _lib.current_stream()), "pf_mfma_probe")
+    torch.cuda.synchronize()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert fl.value == cus * 8 * 24 * 32768 * 50 and sink.item() == 0.0
+    assert lib.pf_mfma_probe(0, 50, C.byref(fl), _lib.current_stream()) < 0
+    assert lib.pf_mfma_probe(sink.data_ptr(), 0, C.byref(fl), _lib.current_stream()) < 0
