@@ -30,6 +30,8 @@ SHAPES = [
     ("g1024_256_768ln", 16, 1, 1024, 256, 0, 768, 1, 1, 0, 3),
     ("g1024_1024_256", 16, 1, 1024, 1024, 0, 256, 1, 1, 0, 0),
     ("g256_256_256", 16, 1, 256, 256, 0, 256, 1, 1, 0, 0),
+    ("gn1024_256_256", 16, 1, 1024, 256, 0, 256, 1, 1, 0, 2),   # SpatialTransformer.proj_in (GroupNorm affine prologue), 32x32 level
+    ("gn256_256_256", 16, 1, 256, 256, 0, 256, 1, 1, 0, 2),      # ... 16x16 level
     ("skip128_192_64", 16, 1, 16384, 128, 64, 64, 1, 1, 0, 0),
     ("p1024_256_256", 16, 1, 1024, 256, 0, 256, 1, 1, 0, 0, 1),
     ("p1024_1024_256", 16, 1, 1024, 1024, 0, 256, 1, 1, 0, 0, 1),
