@@ -7,9 +7,14 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "polyffusion_amd", "csrc")
 f, name, subs = sys.argv[1], sys.argv[2], sys.argv[3:]
 src = open(os.path.join(CSRC, f)).read()
+head = ""
+if os.environ.get("PF_EXP_AFTER"):   # patch only what follows the first occurrence of this marker (e.g. one kernel of several alike)
+    i = src.index(os.environ["PF_EXP_AFTER"])
+    head, src = src[:i], src[i:]
 for old, new in zip(subs[0::2], subs[1::2]):
     assert src.count(old) >= 1, f"pattern not found: {old[:60]}"
     src = src.replace(old, new)
+src = head + src
 out_dir = os.path.join(REPO, "build", "exp")
 os.makedirs(out_dir, exist_ok=True)
 patched = os.path.join(CSRC, f"_exp_{name}_{f}")   # must sit next to its headers

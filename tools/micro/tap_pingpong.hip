@@ -231,5 +231,9 @@ int main() {
   run<1, 0>(src, 1, iters); run<1, 3>(src, 1, iters); run<1, 8>(src, 1, iters);
   run<2, 3>(src, 1, iters); run<2, 8>(src, 1, iters);
   run<3, 3>(src, 1, iters); run<3, 3>(src, 2, iters); run<3, 8>(src, 2, iters);
+#ifdef BIGVALU   // how much vector-ALU work fits beside the partner's MFMA stream (the attention kernel's softmax is ~40 units per 48 MFMAs)
+  run<2, 16>(src, 1, iters); run<2, 24>(src, 1, iters); run<2, 40>(src, 1, iters);
+  run<1, 16>(src, 1, iters); run<1, 24>(src, 1, iters); run<1, 40>(src, 1, iters);
+#endif
   return 0;
 }
