@@ -41,6 +41,7 @@ class UNetPrepared(C.Structure):
 
 
 OPT_MLP_FUSED, OPT_ATTN_WIDE, OPT_CONV_T16, OPT_CONV_PP = 0, 1, 2, 3
+OPT_COUNT = 4              # PF_OPT_COUNT
 OPT_AUTO, OPT_OFF, OPT_ON = -1, 0, 1
 
 

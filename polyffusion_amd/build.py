@@ -17,37 +17,81 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 EXTRA_FLAGS = {"attention_bf3.hip": ["-fno-slp-vectorize"]}
 
 
-def _stale(target: str, deps) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+STAMP = os.path.join(CSRC, ".build_stamp.json")
+
+
+def _digest(paths, extra=()) -> str:
+    """sha256 over the CONTENT of the files and the command line: an object is current only if it was compiled from exactly
+    these bytes with exactly these flags (mtimes say nothing on a snapshot that ships prebuilt objects)."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    for e in extra:
+        h.update(str(e).encode())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def _read_stamp() -> dict:
+    import json
+    try:
+        with open(STAMP) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def _write_stamp(st: dict) -> None:
+    import json
+    with open(STAMP + ".new", "w") as f:
+        json.dump(st, f, indent=1, sort_keys=True)
+    os.replace(STAMP + ".new", STAMP)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile what is not provably current.  `force` (or PF_FORCE_BUILD=1 in the environment) recompiles every translation
+    unit.  Otherwise an object is reused only when the stamp file records, for it, the digest of the source + every header +
+    the flags it would be compiled with now; the library likewise against the digests of its objects."""
+    force = force or os.environ.get("PF_FORCE_BUILD", "") not in ("", "0")
     # every header is a dependency of every object (conv_common.h carries the shared epilogue and the asm helpers)
     hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + [os.path.join(HERE, "..", "include", "pfhip.h")]
-    objs, jobs = [], []
+    stamp = _read_stamp()
+    objs, jobs, want = [], [], {}
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
+        flags = FLAGS + EXTRA_FLAGS.get(src, [])
+        want[src] = _digest([s] + hdrs, flags)
+        if force or not os.path.exists(o) or stamp.get(src) != want[src]:
+            cmd = [HIPCC] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            jobs.append(cmd)
+            jobs.append((src, cmd))
     if jobs:   # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
-            for rc in ex.map(lambda c: subprocess.run(c).returncode, jobs):
-                if rc != 0:
-                    raise subprocess.CalledProcessError(rc, "hipcc")
-    if force or _stale(LIB, objs):
+            rcs = list(ex.map(lambda j: subprocess.run(j[1]).returncode, jobs))
+        for (src, _), rc in zip(jobs, rcs):
+            if rc == 0:
+                stamp[src] = want[src]
+            else:
+                stamp.pop(src, None)
+        _write_stamp(stamp)
+        if any(rcs):
+            raise subprocess.CalledProcessError(max(rcs), "hipcc")
+    elif verbose:
+        print(f"polyffusion_amd.build: {len(SOURCES)} objects current by content digest (PF_FORCE_BUILD=1 recompiles)", flush=True)
+    lib_want = _digest(objs)
+    if force or jobs or not os.path.exists(LIB) or stamp.get("libpfhip.so") != lib_want:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        stamp["libpfhip.so"] = lib_want
+        _write_stamp(stamp)
     return LIB
 
 

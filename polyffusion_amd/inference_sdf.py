@@ -517,39 +517,47 @@ def main(argv=None):
             raise SystemExit(f"--from_dataset {name}: {e} (give --dataset_dir / --split_dir)")
         return sample.get_whole_song_data(), fn
 
+    def need_index(flag, value):
+        # choose_song_from_val_dl asks on stdin when no index is given (ref:inference_sdf.py:95-118): under a multi-rank launch every
+        # rank would block on input() - the index has to come from the command line there
+        if world > 1 and value is None:
+            raise SystemExit(f"{flag} is required when running on more than one rank (no interactive song choice under torchrun)")
+        return value
+
     inp_from_midi = None
     if args.inpaint_type is not None and args.inpaint_from_midi is not None:    # :569-575
         inp_from_midi = song_from_midi(args.inpaint_from_midi, "_inpaint")[0].to(_dev())
         say(f"Inpainting midi file: {args.inpaint_from_midi}")
     elif args.inpaint_type is not None and args.inpaint_from_dataset is not None:   # :576-590
         tracks = [int(v) for v in args.inpaint_pop909_use_track.split(",")] if args.inpaint_pop909_use_track else [0, 1, 2]
-        (p2c, _, _, _), fn = song_from_dataset(args.inpaint_from_dataset, args.inpaint_song_index, tracks)
+        (p2c, _, _, _), fn = song_from_dataset(args.inpaint_from_dataset, need_index("--inpaint_song_index", args.inpaint_song_index), tracks)
         inp_from_midi = p2c.to(_dev())
         say(f"Inpainting midi file: {fn}")
-    if args.from_dataset is not None and args.uncond_scale != 0.0:                # :613-624
-        if args.from_dataset == "musicalion" and params.cond_type == "chord":
-            raise SystemExit("--from_dataset musicalion has no chord track (ref:inference_sdf.py:620 asserts cond_type != 'chord')")
-        (p2c, pnotree, chd, prmat), fn = song_from_dataset(args.from_dataset, args.song_index)
+    if args.uncond_scale != 0.0 and (args.from_midi is not None or args.from_dataset is not None):
+        # the reference's order (:604-624): a MIDI file wins over a dataset song when both are given
+        if args.from_midi is not None:
+            p2c, pnotree, chd, prmat = song_from_midi(args.from_midi, "")
+            fn = args.from_midi
+        else:
+            if args.from_dataset == "musicalion" and "chord" in params.cond_type.split("+"):
+                raise SystemExit("--from_dataset musicalion has no chord track (ref:inference_sdf.py:620 asserts cond_type != 'chord'; "
+                                 "a chord+txt model would receive chd = None)")
+            (p2c, pnotree, chd, prmat), fn = song_from_dataset(args.from_dataset, need_index("--song_index", args.song_index))
         chd = None if chd is None else chd.to(_dev())
         prmat, prmat2c_cond, pnotree = prmat.to(_dev()), p2c.to(_dev()), pnotree.to(_dev())
         say(f"using the {params.cond_type.split('+')[0]} of midi file: {fn}")
-        if params.cond_type == "chord+txt" and args.from_midi2 is None:           # texture from a second song of the set (:636-641)
-            (_, _, _, prmat2), fn2 = song_from_dataset(args.from_dataset, args.song_index2)
-            prmat = prmat2.to(_dev())
-            say(f"using the txt of midi file: {fn2}")
-        elif params.cond_type == "chord+txt":
-            prmat = song_from_midi(args.from_midi2, "")[3].to(_dev())
-            say(f"using the txt of midi file: {args.from_midi2}")
+        if params.cond_type == "chord+txt":                                       # texture from a second song (:627-641)
+            if args.from_midi2 is not None:
+                prmat = song_from_midi(args.from_midi2, "")[3].to(_dev())
+                say(f"using the txt of midi file: {args.from_midi2}")
+            elif args.from_dataset is not None:
+                (_, _, _, prmat2), fn2 = song_from_dataset(args.from_dataset, need_index("--song_index2", args.song_index2))
+                prmat = prmat2.to(_dev())
+                say(f"using the txt of midi file: {fn2}")
+            # else (an extension; the reference raises NotImplementedError): chords and texture both from --from_midi
     elif args.from_song_npz is not None:
         p2c, pnotree, chd, prmat = datasample.DataSample.from_npz(args.from_song_npz).get_whole_song_data()
         chd, prmat, prmat2c_cond, pnotree = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev()), pnotree.to(_dev())
-    elif args.from_midi is not None and args.uncond_scale != 0.0:
-        p2c, pnotree, chd, prmat = song_from_midi(args.from_midi, "")
-        chd, prmat, prmat2c_cond, pnotree = chd.to(_dev()), prmat.to(_dev()), p2c.to(_dev()), pnotree.to(_dev())
-        say(f"using the {params.cond_type.split('+')[0]} of midi file: {args.from_midi}")
-        if params.cond_type == "chord+txt" and args.from_midi2 is not None:      # texture from a second file (:630-635)
-            prmat = song_from_midi(args.from_midi2, "")[3].to(_dev())
-            say(f"using the txt of midi file: {args.from_midi2}")
     elif args.uncond_scale == 0.0 and args.cond_npz is None and not args.synthetic:
         if length <= 0 and inp_from_midi is not None:
             length = inp_from_midi.shape[0]            # :596-597

@@ -61,6 +61,10 @@ class DiffusionSampler:
         # key = everything that shapes the captured launch sequence, value = the graph + the static buffers its nodes point at
         self._graphs = {}
         self.graph_captures = 0
+        # on_step(step, x): called by the eager loops of paint() after every reverse step with the step's number and its result
+        # (the reference's `is_show_image` hook, sampler_sdf.py:338-345, as a callback).  None = no call, no cost.  Used by the
+        # full-length parity runs (tools/long_parity.py) to record how two arithmetic modes drift apart along one noise tape.
+        self.on_step: Optional[Callable[[int, torch.Tensor], None]] = None
 
     def _step_state(self, device) -> torch.Tensor:
         key = ("state", str(device))
@@ -80,7 +84,7 @@ class DiffusionSampler:
         ws = getattr(m, "_ws", None)
         blob = getattr(m, "_blob_dev", None)
         return (0 if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(), 0 if blob is None else blob.data_ptr(),
-                getattr(m, "precision", None))
+                getattr(m, "precision", None)) + (m.options_key() if hasattr(m, "options_key") else ())
 
     def _graph_for(self, key, inputs, make_body, reset, uncond_scale=1.0):
         """The captured step for `key`, with `inputs` (name -> tensor or None) copied into its static buffers.  A cached entry is
@@ -198,10 +202,14 @@ class DiffusionSampler:
         xin = x if cond_concat is None else torch.cat([x, cond_concat], dim=1)
         return self.get_eps(xin, t, c, uncond_scale=uncond_scale, uncond_cond=uncond_cond, prep=prep)
 
-    def _rng_ok(self, x) -> bool:
-        """The in-kernel noise path: on-device generator, whole Philox groups per tensor and per shard."""
+    def _rng_ok(self, x, *others) -> bool:
+        """The in-kernel noise path: on-device generator, whole Philox groups per tensor and per shard, and every tensor the
+        update kernel reads as 16-byte vectors (x and, when present, orig / orig_noise / mask) contiguous and 16-byte aligned -
+        anything else takes the randn() + step path, which has no such requirement."""
         per_sample = x.numel() // x.shape[0]
-        return self.noise_fn is None and x.numel() % 4 == 0 and (self.sample_offset * per_sample) % 4 == 0
+        if self.noise_fn is not None or x.numel() % 4 != 0 or (self.sample_offset * per_sample) % 4 != 0:
+            return False
+        return all(v is None or (v.is_contiguous() and v.data_ptr() % 16 == 0) for v in (x,) + others)
 
 
 class SDFSampler(DiffusionSampler):
@@ -341,9 +349,10 @@ class SDFSampler(DiffusionSampler):
         ``bench.py`` times exactly this method."""
         lib, step, n = self._lib, int(step), x_t.numel()
         coef = self._coef(step)
+        x_t = x_t.contiguous()
         e_t = self._eps(x_t, cond, step, uncond_scale, uncond_cond, cond_concat, prep)
         x = torch.empty_like(x_t)
-        if step > 0 and self._rng_ok(x_t):
+        if step > 0 and self._rng_ok(x_t, orig, mask):
             _lib.check(lib.pf_ddpm_step_rng(x_t.data_ptr(), e_t.data_ptr(), orig.data_ptr(), mask.data_ptr(), C.byref(coef), self.seed,
                                             self._draws, self._draws + 1, self.sample_offset * (n // x_t.shape[0]), x.data_ptr(), n,
                                             _lib.current_stream()), "pf_ddpm_step_rng")
@@ -353,6 +362,7 @@ class SDFSampler(DiffusionSampler):
         # evaluation, p after it - randn() only counts draws, so drawing both here keeps the tape aligned
         noise_q = self.randn(orig.shape, x_t.device) if step > 0 else None
         noise_p = self.randn(x_t.shape, x_t.device) if step > 0 else None
+        orig, mask = orig.contiguous(), mask.contiguous()
         _lib.check(lib.pf_ddpm_step(x_t.data_ptr(), e_t.data_ptr(), _lib.ptr(noise_p), _lib.ptr(noise_q), orig.data_ptr(), mask.data_ptr(),
                                     C.byref(coef), x.data_ptr(), n, _lib.current_stream()), "pf_ddpm_step")
         return x
@@ -368,7 +378,7 @@ class SDFSampler(DiffusionSampler):
             orig, mask = orig.contiguous().float(), mask.contiguous().float()
         n = x.numel()
         steps = np.flip(self.time_steps[: t_start + 1])
-        if self.graph and self.noise_fn is None and repaint_n == 1 and t_start >= 1:
+        if self.graph and self.noise_fn is None and repaint_n == 1 and t_start >= 1 and self.on_step is None:
             x = self._paint_graph(x, cond, int(t_start), orig, mask, uncond_scale, uncond_cond, cond_concat)
             steps = steps[-1:]          # step 0 (no noise) runs eagerly below
         # everything the denoiser derives from (t, cond) alone, once for the whole loop
@@ -378,6 +388,8 @@ class SDFSampler(DiffusionSampler):
             if orig is None:
                 x, _, _ = self.p_sample(x, cond, None, step, uncond_scale=uncond_scale, uncond_cond=uncond_cond,
                                         cond_concat=cond_concat, return_x0=False, prep=prep)
+                if self.on_step is not None:
+                    self.on_step(step, x)
                 continue
             x_t = x
             for u in range(repaint_n):
@@ -389,6 +401,8 @@ class SDFSampler(DiffusionSampler):
                     x_t = torch.empty_like(x)
                     _lib.check(lib.pf_axpby(x.data_ptr(), noise.data_ptr(), float((1 - b) ** 0.5), float(b),
                                             x_t.data_ptr(), n, stream()), "pf_axpby")
+            if self.on_step is not None:
+                self.on_step(step, x)
         return x
 
 
@@ -478,7 +492,7 @@ class DDIMSampler(DiffusionSampler):
         coef = self._coef(index)
         noise = None
         noisy = float(self.ddim_sigma[index]) != 0.0
-        if noisy and not repeat_noise and temperature == 1.0 and self._rng_ok(x):
+        if noisy and not repeat_noise and temperature == 1.0 and self._rng_ok(x, e_t, orig, orig_noise, mask):
             # the step's draw happens inside the update kernel (same values as randn() + pf_ddim_step)
             draw = self._draws
             self._draws += 1
@@ -548,7 +562,7 @@ class DDIMSampler(DiffusionSampler):
             orig, mask = orig.contiguous().float(), mask.contiguous().float()
             orig_noise = None if orig_noise is None else orig_noise.contiguous().float()
         time_steps = np.flip(self.time_steps[: t_start + 1])
-        if self.graph and self.noise_fn is None and (orig is None or orig_noise is not None):
+        if self.graph and self.noise_fn is None and (orig is None or orig_noise is not None) and self.on_step is None:
             nonzero = self.ddim_sigma[: t_start + 1] != 0
             if not bool(nonzero.any()) or bool(nonzero.all()):    # a mixed range would need a per-step decision on the host
                 return self._paint_graph(x, cond, int(t_start), orig, mask, orig_noise, uncond_scale, uncond_cond, cond_concat,
@@ -559,4 +573,6 @@ class DDIMSampler(DiffusionSampler):
             e_t = self._eps(x, cond, int(step), uncond_scale, uncond_cond, cond_concat, prep)
             # x_prev and the known-region blend (fixed orig_noise, sampler_ddim.py:355-359) in one kernel
             x, _ = self._step(x, e_t, index, orig=orig, orig_noise=orig_noise, mask=mask)
+            if self.on_step is not None:
+                self.on_step(int(step), x)
         return x

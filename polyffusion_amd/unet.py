@@ -111,7 +111,7 @@ class UNetModel:
     # ---- forward --------------------------------------------------------------------------------
     def workspace(self, batch: int, n_cond: int) -> torch.Tensor:
         # tile choice (and buffer sizes) depend on the arithmetic mode and on the plan options
-        key = (batch, n_cond, self._lib.pf_unet_get_precision(self._h)) + tuple(self._lib.pf_unet_get_option(self._h, o) for o in range(3))
+        key = (batch, n_cond, self._lib.pf_unet_get_precision(self._h)) + self.options_key()
         if self._ws is None or self._ws_key != key:
             nbytes = self._lib.pf_unet_workspace_bytes(self._h, batch, n_cond)
             if self._ws is None or self._ws.numel() < nbytes:
@@ -156,9 +156,11 @@ class UNetModel:
         return out
 
     def forward(self, x: torch.Tensor, time_steps: torch.Tensor, cond: torch.Tensor, out: Optional[torch.Tensor] = None, *,
-                time_table: Optional[torch.Tensor] = None, cross_bias: Optional[torch.Tensor] = None):
+                time_table: Optional[torch.Tensor] = None, cross_bias: Optional[torch.Tensor] = None, check_t: bool = False):
         """``time_table`` / ``cross_bias``: results of ``prepare_time`` / ``prepare_cond(cond)`` - the caller vouches that they
-        belong to these weights and this ``cond``; either may be ``None`` (computed here).  Bit-identical either way."""
+        belong to these weights and this ``cond``; either may be ``None`` (computed here).  Bit-identical either way.
+        The prepared path is valid for ``0 <= t < time_table.shape[0]`` only; ``check_t=True`` verifies that (one device->host
+        sync - the samplers, whose t values are rows of a host-built table, do not ask for it)."""
         if self._blob_dev is None:
             raise RuntimeError("UNetModel.forward: weights not loaded")
         B = x.shape[0]
@@ -178,6 +180,14 @@ class UNetModel:
             prep = _lib.UNetPrepared()
             if time_table is not None:
                 assert time_table.dtype == torch.float32 and time_table.is_contiguous() and time_table.device == x.device
+                # the kernels clamp a row index into the table for memory safety only: a t outside it would silently read the
+                # wrong row.  Callers that hold t on the host say so (check_t); the samplers' loops index a [n_steps+1]-row table
+                # with values < n_steps + 1 by construction.
+                if check_t:
+                    lo, hi = int(t.min()), int(t.max())
+                    if lo < 0 or hi >= time_table.shape[0]:
+                        raise RuntimeError(f"UNetModel.forward: time step {lo if lo < 0 else hi} outside the prepared table "
+                                           f"({time_table.shape[0]} rows)")
                 prep.time_table, prep.n_time_rows = time_table.data_ptr(), time_table.shape[0]
             if cross_bias is not None:
                 assert n_cond == 1 and cross_bias.shape[0] == B and cross_bias.is_contiguous() and cross_bias.device == x.device
@@ -212,6 +222,10 @@ class UNetModel:
     def get_option(self, name: str) -> Optional[bool]:
         v = self._lib.pf_unet_get_option(self._h, self._OPTS[name])
         return None if v < 0 else bool(v)
+
+    def options_key(self) -> tuple:
+        """Every plan option's current setting: part of the key of anything that bakes the launch sequence in (workspace, graphs)."""
+        return tuple(self._lib.pf_unet_get_option(self._h, o) for o in range(_lib.OPT_COUNT))
 
     # ---- profiling ------------------------------------------------------------------------------
     def set_profiling(self, on: bool):
