@@ -73,7 +73,7 @@ def time_step_embedding(t: torch.Tensor, channels: int, max_period: float = 1000
 
 def time_embed(w: Tensors, t: torch.Tensor, channels: int) -> torch.Tensor:
     """unet.py:63-68,181-182 - Linear, SiLU, Linear on the sinusoid."""
-    e = time_step_embedding(t, channels)
+    e = time_step_embedding(t, channels).to(w["time_embed.0.weight"].dtype)   # fp32 like the reference; float64 weights = the truth runs of the stress tests
     e = F.linear(e, w["time_embed.0.weight"], w["time_embed.0.bias"])
     return F.linear(F.silu(e), w["time_embed.2.weight"], w["time_embed.2.bias"])
 

@@ -50,22 +50,39 @@ _direct_comm = None
 
 
 def _direct(rank: int, world: int):
-    """pf_comm over librccl directly (include/pfhip.h): the 128-byte unique id travels through a TCPStore next to
-    the torchrun rendezvous port; no torch.distributed process group is involved."""
+    """pf_comm over librccl directly (include/pfhip.h): the 128-byte unique id travels through the process group the
+    launcher's rendezvous already set up (or, without one, a TCPStore on PF_COMM_PORT / MASTER_PORT + 1); the broadcast of the
+    weight blobs itself involves no torch.distributed collective."""
     global _direct_comm
     if _direct_comm is None:
         import ctypes as C
         from datetime import timedelta
         from . import _lib
         lib = _lib.load()
-        host, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 1
-        store = dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=timedelta(seconds=120))
         uid = (C.c_char * 128)()
         if rank == 0:
             _lib.check(lib.pf_comm_unique_id(uid), "pf_comm_unique_id")
-            store.set("pf_comm_uid", bytes(uid.raw))
+        store = None
+        if dist.is_available() and dist.is_initialized():
+            # the launcher's own rendezvous carries the id: no second listening port that could be taken on the node
+            box = [bytes(uid.raw) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            if rank != 0:
+                uid.raw = box[0]
         else:
-            uid.raw = store.get("pf_comm_uid")
+            # no process group: a TCPStore of our own.  PF_COMM_PORT names its port; default MASTER_PORT + 1 (rank 0 cannot tell the
+            # others a probed port without a channel, so the number has to be agreed on beforehand)
+            host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+            port = int(os.environ.get("PF_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+            try:
+                store = dist.TCPStore(host, port, world, is_master=(rank == 0), timeout=timedelta(seconds=120))
+            except (RuntimeError, OSError) as e:
+                raise RuntimeError(f"PF_COMM_DIRECT: cannot open the id-exchange store on {host}:{port} ({e}); set PF_COMM_PORT to a free port "
+                                   "(the same on every rank)") from e
+            if rank == 0:
+                store.set("pf_comm_uid", bytes(uid.raw))
+            else:
+                uid.raw = store.get("pf_comm_uid")
         h = C.c_void_p()
         _lib.check(lib.pf_comm_init(uid, rank, world, C.byref(h)), "pf_comm_init")
         _direct_comm = (lib, h, store)

@@ -238,6 +238,34 @@ def build_unet(params, device=None) -> UNetModel:
                      d_cond=params.d_cond, img_h=params.img_h, img_w=params.img_w, device=device)
 
 
+PRECISION_PROBE_TOL = 3e-4
+
+
+def pick_precision(unet: UNetModel, cond: torch.Tensor, tol: float = PRECISION_PROBE_TOL, n_steps: int = 1000, seed: int = 0):
+    """``--precision auto``: choose the arithmetic mode by MEASURING this network.  bf16x3 (three bf16 MFMAs per product, unit
+    roundoff ~2^-18) is ~3x faster than the exact-fp32-MFMA mode and sits 5e-5 from the reference on ordinarily-conditioned
+    weights, but every rounding error is amplified by the network's conditioning - fp32's too - and on badly-scaled weights the
+    split can exceed the 1e-3 contract (tests/test_gpu_long_parity.py, tools/stress_diag.py).  One evaluation in each mode on three
+    probe samples (Gaussian x at t = n_steps-1, n_steps/2 and 0, the first rows of the run's own ``cond``); bf16x3 is kept only if
+    ``max|eps_bf16x3 - eps_f32| <= tol * max|eps_f32|`` (default 3e-4: a third of the contract).  Sets the mode on ``unet`` and
+    returns ``(mode, measured ratio)``.  Cost: two evaluations of a loop that runs 50-1000."""
+    lib = _lib.load()
+    n = 3
+    x = torch.empty(n, unet.cfg.in_channels, unet.img_h, unet.img_w, dtype=torch.float32, device=cond.device)
+    _lib.check(lib.pf_randn(x.data_ptr(), x.numel(), int(seed) + 0x5eed, 0, 0, _lib.current_stream()), "pf_randn")
+    t = torch.tensor([n_steps - 1, n_steps // 2, 0], device=cond.device)
+    c = cond[torch.arange(n, device=cond.device) % cond.shape[0]].contiguous()
+    unet.set_precision("f32")
+    ref = unet(x, t, c).clone()
+    unet.set_precision("bf16x3")
+    got = unet(x, t, c)
+    scale = ref.abs().max().item()
+    ratio = float("inf") if not (scale > 0 and bool(torch.isfinite(got).all())) else (got - ref).abs().max().item() / scale
+    mode = "bf16x3" if ratio <= tol else "f32"
+    unet.set_precision(mode)
+    return mode, ratio
+
+
 def build_ldm(params, unet: UNetModel) -> LatentDiffusion:
     return LatentDiffusion(linear_start=params.linear_start, linear_end=params.linear_end, n_steps=params.n_steps,
                            latent_scaling_factor=params.latent_scaling_factor, autoencoder=None, unet_model=unet)
@@ -345,6 +373,9 @@ def make_parser() -> ArgumentParser:
                    "db_pos_filter, chord - what get_data_for_single_midi / the POP909 .npz files hold): its 8-bar segments supply the "
                    "chord / texture conditions and the image to inpaint (ref:inference_sdf.py:599-610 via data/datasample.py)")
     p.add_argument("--bar_list", help="bars to inpaint for --inpaint_type bars, comma separated")
+    p.add_argument("--precision", choices=["auto", "f32", "bf16x3"], default="auto", help="arithmetic of the denoiser's contractions: f32 = exact "
+                   "fp32 MFMA; bf16x3 = error-compensated bf16 split (about 3x faster, 5e-5 from the reference on ordinarily-conditioned weights); "
+                   "auto (default) = evaluate both once on this checkpoint and keep bf16x3 only if they agree to 3e-4 of the output scale")
     p.add_argument("--hip_graph", action="store_true", help="capture one reverse step as a hipGraph and replay it (same results; "
                    "removes the host-side launch cost that bounds small batches, e.g. the batch-1 runs of --autoreg)")
     return p
@@ -611,6 +642,13 @@ def main(argv=None):
         cond, cond_concat = cond[:n], cond_concat[:n]
         cond_mid = None if cond_mid is None else cond_mid[:n]
         orig, mask = (None if v is None else v[:n] for v in (orig, mask))
+    if args.precision == "auto":
+        mode, ratio = pick_precision(model.ldm.eps_model, cond.reshape(-1, *cond.shape[-2:]), n_steps=params.n_steps, seed=seed)
+        mode = ["f32", "bf16x3"][pfdist.broadcast_int(int(mode == "bf16x3"))]        # one decision for all ranks (rank 0's)
+        model.ldm.eps_model.set_precision(mode)
+        say(f"precision: {mode} (bf16x3 vs f32 on probe inputs: {ratio:.1e} of the output scale, threshold {PRECISION_PROBE_TOL:.0e})")
+    else:
+        model.ldm.eps_model.set_precision(args.precision)
     S, B = args.num_generate, cond.shape[0]
     say(f"generating {S} song(s) x {B} segment(s) with uncond_scale = {args.uncond_scale} on {world} GPU(s)")
     gen, expmt = generate_songs(model, params, args, cond, cond_mid, orig, mask, seed, rank, world, cond_concat=cond_concat)
