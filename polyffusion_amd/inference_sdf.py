@@ -26,7 +26,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import datasample, midi, synth
+from . import _lib, datasample, midi, synth
 from .model_sdf import ChordEncoder, Polyffusion_SDF, TextureEncoder
 from .params import Params, find_params, load_params, preset
 from .sampler import DDIMSampler, DiffusionSampler, SDFSampler

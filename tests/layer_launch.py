@@ -102,6 +102,11 @@ class Launch:
             self.keep += [sx0, sx1, sw]
             skip_k = sc0 + sc1
         self.gflop = 2.0 * B * ho * wo * n * (cin * taps + skip_k) / 1e9
+        wsb = int(lib.pf_conv_splitk_ws_bytes(C.byref(a)))   # a layer the library would split over K gets the scratch the plan gives it
+        if wsb:
+            ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+            a.splitk_ws, a.splitk_ws_bytes = ws.data_ptr(), wsb
+            self.keep.append(ws)
 
     def run(self, check: bool = True):
         rc = self.lib.pf_conv2d(C.byref(self.args), torch.cuda.current_stream().cuda_stream)

@@ -12,7 +12,12 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 import layer_launch  # noqa: E402
 
-EXTRA = []   # same tuple format as layer_launch.SHAPES
+EXTRA = [   # same tuple format as layer_launch.SHAPES
+    ("rs16_256_256", 16, 16, 16, 256, 0, 256, 3, 1, 0, 1, 7, 256, 256),
+    ("r16b8_256_256", 8, 16, 16, 256, 0, 256, 3, 1, 0, 1),
+    ("r16b8_256+256_256", 8, 16, 16, 256, 256, 256, 3, 1, 0, 1),
+    ("r32b8_256_256", 8, 32, 32, 256, 0, 256, 3, 1, 0, 1),
+]
 
 
 def main():
