@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["conv_mfma.hip", "conv_bf16x3.hip", "gemm_planes_bf3.hip", "mlp_fused_bf3.hip", "attention.hip", "attention_bf3.hip", "norm_stats.hip", "small_kernels.hip", "encoders.hip", "comm.hip", "unet.hip"]
+SOURCES = ["conv_mfma.hip", "conv_bf16x3.hip", "gemm_planes_bf3.hip", "mlp_fused_bf3.hip", "preattn_fused_bf3.hip", "attention.hip", "attention_bf3.hip", "norm_stats.hip", "small_kernels.hip", "encoders.hip", "comm.hip", "unet.hip"]
 LIB = os.path.join(HERE, "libpfhip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + (["-DPF_TRACE"] if os.environ.get("PF_TRACE") else [])

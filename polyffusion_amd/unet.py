@@ -211,7 +211,7 @@ class UNetModel:
         return ["f32", "bf16x3"][self._lib.pf_unet_get_precision(self._h)]
 
     # ---- plan options (which of two equivalent kernel forms the plan launches; include/pfhip.h PF_OPT_*) --------
-    _OPTS = {"mlp_fused": _lib.OPT_MLP_FUSED, "attn_wide": _lib.OPT_ATTN_WIDE, "conv_t16": _lib.OPT_CONV_T16, "conv_pp": _lib.OPT_CONV_PP}
+    _OPTS = {"mlp_fused": _lib.OPT_MLP_FUSED, "attn_wide": _lib.OPT_ATTN_WIDE, "conv_t16": _lib.OPT_CONV_T16, "conv_pp": _lib.OPT_CONV_PP, "pre_fused": _lib.OPT_PRE_FUSED}
 
     def set_option(self, name: str, value: Optional[bool]):
         """``None`` = automatic (the default), ``False`` / ``True`` = never / always (where the form exists)."""

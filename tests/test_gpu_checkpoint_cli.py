@@ -197,7 +197,8 @@ def test_cli_concat_blurry_params(tmp_path):
     np.savez(tmp_path / "cond.npz", chord=synth.chords(n, 32), prmat2c=img)
     out = tmp_path / "out"
     argv = ["--custom_params_path", str(tmp_path / "params.yaml"), "--synthetic_weights", "--cond_npz", str(tmp_path / "cond.npz"),
-            "--ddim", "--ddim_steps", "4", "--uncond_scale", "2.0", "--seed", "5", "--num_generate", "2", "--output_dir", str(out)]
+            "--ddim", "--ddim_steps", "4", "--uncond_scale", "2.0", "--seed", "5", "--num_generate", "2", "--output_dir", str(out),
+            "--precision", "f32"]     # the hand-built model below runs the library default (exact fp32 MFMA); the CLI's own default is `auto`
     assert inference_sdf.main(argv) == 0
     npys = sorted(f for f in os.listdir(out) if f.endswith(".npy"))
     assert len(npys) == 2
