@@ -361,7 +361,7 @@ def main():
                     help="arithmetic of the dense contractions: exact fp32 MFMA, or the error-compensated bf16x3 split")
     ap.add_argument("--dump-launches", action="store_true", help="print one line per kernel launch of a profiled step (stderr)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=0|1",
-                    help="pin a plan option of the UNet handle (pf_unet_set_option: mlp_fused, attn_wide, conv_t16, conv_pp) for A/B runs; "
+                    help="pin a plan option of the UNet handle (pf_unet_set_option: mlp_fused, attn_wide, conv_t16, conv_pp, pre_fused) for A/B runs; "
                          "the default line runs with every option automatic")
     args = ap.parse_args()
 
@@ -443,7 +443,7 @@ def main():
         "path_tflops": round(f_eval * BATCH * world * args.steps / elapsed / 1e12, 3),
         "path_frac_of_f32_mfma_peak": round(f_eval * BATCH * args.steps / elapsed / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
         "path_flops_per_sample_eval": f_eval,
-        "plan_options": {n: unet.get_option(n) for n in ("mlp_fused", "attn_wide", "conv_t16", "conv_pp")},
+        "plan_options": {n: unet.get_option(n) for n in ("mlp_fused", "attn_wide", "conv_t16", "conv_pp", "pre_fused")},
         "precision_note": ("dense contractions on the bf16 matrix pipe as an error-compensated split (3 MFMAs per product, fp32 accumulate); "
                            "UNet max-abs-diff vs the reference 5.2e-5 (contract 1e-3)") if args.precision == "bf16x3"
         else "dense contractions on the fp32 matrix pipe (exact fp32 FMA chains)",

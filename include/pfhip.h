@@ -108,8 +108,8 @@ int pf_unet_n_launches_prepared(const pf_unet* u, int batch, int n_cond, int has
  *   PF_OPT_CONV_PP    - 3x3 convs whose 128-wide tiles give every CU at most one workgroup (B = 16: the 32x32 level) as 8-wave workgroups:
  *                       two wave groups split K and run half a tap apart, one loading while the other computes (equal up to summation order)
  *   PF_OPT_PRE_FUSED  - the pre-attention half of a SpatialTransformer's first layer (GroupNorm + proj_in + LayerNorm1 + q|k|v projection,
- *                       pf_preattn_fused) as ONE launch per 64-token tile vs three launches; equal up to summation order; auto: when the
- *                       64-token tiles fill >= 85 % of the last round of CUs (d_model 256 only) */
+ *                       pf_preattn_fused) as ONE launch per 64-token tile vs three launches; equal up to summation order; auto = off
+ *                       (measured neutral end to end, profiles/r05_ab_pre_fused.md); on: every block with d_model 256 and L % 64 == 0 */
 enum { PF_OPT_MLP_FUSED = 0, PF_OPT_ATTN_WIDE = 1, PF_OPT_CONV_T16 = 2, PF_OPT_CONV_PP = 3, PF_OPT_PRE_FUSED = 4, PF_OPT_COUNT = 5 };
 enum { PF_OPT_AUTO = -1, PF_OPT_OFF = 0, PF_OPT_ON = 1 };
 int pf_unet_set_option(pf_unet* u, int option, int value);

@@ -28,6 +28,13 @@ struct PreX {
 
 typedef __bf16 bf16x4_p __attribute__((ext_vector_type(4)));
 
+// cycle stamps of workgroup 0 (tools/trace_pre.py builds a -DPF_PRE_TRACE copy; the buffer pointer travels in ConvP::mean, unused here)
+#ifdef PF_PRE_TRACE
+#define TRP() do { if (tr) { *tr++ = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define TRP() do {} while (0)
+#endif
+
 template <int RING>
 __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
   constexpr int BM = 64, C = 256, NSTEP = C / 16;
@@ -55,6 +62,10 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
   const int ox0 = (lid - b * p.tiles_x) * BM;
   const size_t row0 = (size_t)b * L + ox0;
 
+#ifdef PF_PRE_TRACE
+  unsigned long long* tr = (blockIdx.x == 0 && threadIdx.x == 0) ? reinterpret_cast<unsigned long long*>(const_cast<float*>(p.mean)) : nullptr;
+#endif
+  TRP();
   // ---- weight stream: 16-deep step `kstep` of a [256][npad] matrix, columns ncol0 .. ncol0 + 255, piece q (1 KiB per wave) into ring position pos
   const __amdgpu_buffer_rsrc_t g_in = dma_resource(e.w_in), g_qkv = dma_resource(e.w_qkv);
   const int vn = tid * 16;
@@ -71,7 +82,9 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
   f32x4 v[RPW];
 #pragma unroll
   for (int i = 0; i < RPW; ++i) v[i] = *reinterpret_cast<const f32x4*>(p.x0 + (row0 + wave * RPW + i) * C + lane * 4);
+  TRP();
   if (p.gn_s0) gn_fused_prologue<256>(p, b, tid, p.Hin * p.Win, reinterpret_cast<double*>(sP));   // finalize folded into this launch
+  TRP();
   {
     const f32x4 sc = *reinterpret_cast<const f32x4*>(p.sc + (size_t)b * C + lane * 4);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(p.sh + (size_t)b * C + lane * 4);
@@ -88,6 +101,7 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
     }
   }
 
+  TRP();
   // ---- fragment addresses (mlp_fused_bf3.hip's) ----
   const unsigned ldsA = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)sA;
   const unsigned ldsR = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)sR;
@@ -130,6 +144,7 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 2) * 4) : "memory");   // slot 0 landed; this thread's plane stores are done
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    TRP();
     static_for<0, 10>([&](auto n) { ld(IC(0), IC(0), IC(0), n); });
     SB();
     static_for<0, NSTEP>([&](auto cc) {
@@ -146,22 +161,37 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
       });
     });
     SB();
+    TRP();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     SB();
+    TRP();
   };
 
   // ================= proj_in =================
   gemm_pass(g_in, C, 0);
+  // small operands of the exchange, fetched while nothing else is in flight (a compiler-visible load behind the weight copies issued
+  // below would make hipcc drain them before its first use)
+  const int cq = (lane & 31) & ~3;
+  f32x4 b4[4];
+#pragma unroll
+  for (int fn = 0; fn < 4; ++fn) b4[fn] = *reinterpret_cast<const f32x4*>(e.b_in + wn * 128 + fn * 32 + cq);
+  f32x4 g = *reinterpret_cast<const f32x4*>(e.gamma + lane * 4), be = *reinterpret_cast<const f32x4*>(e.beta + lane * 4);
+#pragma unroll
+  for (int fn = 0; fn < 4; ++fn) asm volatile("" : "+v"(b4[fn]));
+  asm volatile("" : "+v"(g), "+v"(be));
   __builtin_amdgcn_s_barrier();     // every wave is done with the planes and the ring
   asm volatile("" ::: "memory");
+  // the first slots of q|k|v pass 0 start now: their latency (a first touch of w_qkv: HBM) hides behind the exchange below, which
+  // therefore stages through the planes region - the ring is busy
+#pragma unroll
+  for (int d = 0; d < RING - 1; ++d)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue(g_qkv, 3 * C, 0, d, d, q);
   {
     // y = acc + bias: accumulators -> LDS as fp32 rows (lane-quad transpose: a lane stores four consecutive channels of one token; the 16-byte
-    // slot of a row is XOR-ed with (row & 3) << 2 so the 16 lanes of a store pass hit 16 different slots), then one wave per row
-    float* sY = reinterpret_cast<float*>(sR);
-    const int cq = (lane & 31) & ~3;
-    f32x4 b4[4];
-#pragma unroll
-    for (int fn = 0; fn < 4; ++fn) b4[fn] = *reinterpret_cast<const f32x4*>(e.b_in + wn * 128 + fn * 32 + cq);
+    // slot of a row is XOR-ed with (row & 3) << 2 so the 16 lanes of a store pass hit 16 different slots), then one wave per row.
+    // Raw barriers with LDS-only waits: a __syncthreads() would also wait for the weight copies just issued.
+    float* sY = reinterpret_cast<float*>(sA);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = wm * 32 + 8 * q + 4 * (lane >> 5) + (lane & 3);
@@ -178,16 +208,20 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
     for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][fn][r] = 0.f;
-    __syncthreads();
-    const f32x4 g = *reinterpret_cast<const f32x4*>(e.gamma + lane * 4), be = *reinterpret_cast<const f32x4*>(e.beta + lane * 4);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    TRP();
     float red[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const int row = wave * RPW + i;
       v[i] = *reinterpret_cast<const f32x4*>(sY + row * C + ((lane ^ ((row & 3) << 2)) << 2));
     }
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) *reinterpret_cast<f32x4*>(e.y + (row0 + wave * RPW + i) * C + lane * 4) = v[i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // every wave holds its rows: the region may become planes again
+    asm volatile("" ::: "memory");
+    TRP();
     // LayerNorm1: ln_planes_kernel's arithmetic (xor butterfly 32, 16, .., 1), the 16 rows' reductions advancing together
 #pragma unroll
     for (int i = 0; i < RPW; ++i) red[i] = (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -217,27 +251,65 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
       *reinterpret_cast<bf16x4_p*>(d) = hi;
       *reinterpret_cast<bf16x4_p*>(d + LO_B) = lo;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row stores: the passes below count their own loads only
-    __syncthreads();                                    // nobody reads the staging rows any more: the ring may be refilled
+    // (the pass's own opening wait + barrier publishes the planes; the fp32 rows v[] go to HBM at the very end of the kernel: stores
+    // issued here would sit in the same counter as the weight copies and every slot hand-over would wait for the write burst)
+    TRP();
   }
 
   // ================= q | k | v: three 256-column passes over the LayerNorm planes =================
-#pragma unroll 1
-  for (int pass = 0; pass < 3; ++pass) {
+  // Q and K thirds ([token][C] plane pairs) leave straight from the accumulators: lane-quad transpose, hi/lo split, 8-byte stores (eight
+  // lanes cover 64 contiguous bytes of a row).  With one wave per SIMD every vector instruction is exposed, and conv_epilogue's staged
+  // writer (64 LDS writes, two barriers, 8 x 60 instructions per lane) cost 6-7.6 k cycles per pass in the cycle stamps against 7.2 k for
+  // the pass's MFMAs; it also needs the ring as staging, which kept the next pass's first slots from being fetched meanwhile.  Same values,
+  // same conversions: the planes are bit-identical to the staged writer's.
+  auto store_qk = [&](int which) {
+    const size_t MC = (size_t)p.B * L * C;
+    __bf16* ph = static_cast<__bf16*>(p.qkv) + (size_t)(2 * which) * MC;
+    const int cq = (lane & 31) & ~3;
 #pragma unroll
-    for (int d = 0; d < RING - 1; ++d)
+    for (int q = 0; q < 4; ++q) {
+      const int row = wm * 32 + 8 * q + 4 * (lane >> 5) + (lane & 3);
+      __bf16* pr = ph + (row0 + row) * C + wn * 128 + cq;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) issue(g_qkv, 3 * C, pass * C, d, d, q);
-    gemm_pass(g_qkv, 3 * C, pass * C);
-    // Q / K thirds: [token][C] plane pairs; V third: V^T [head][d][token] - conv_epilogue's writers, staged through the (idle) ring region
-    conv_epilogue<1, BM, C, 1, 4, 2>(p, acc, b, 0, ox0, pass * C, wm, wn, lane, tid, reinterpret_cast<float*>(sR));
+      for (int fn = 0; fn < 4; ++fn) {
+        f32x4 t = {acc[0][fn][4 * q], acc[0][fn][4 * q + 1], acc[0][fn][4 * q + 2], acc[0][fn][4 * q + 3]};
+        quad_transpose(t, lane);
+        const bf16x4_p hi = __builtin_convertvector(t, bf16x4_p);
+        const bf16x4_p lo = __builtin_convertvector(t - __builtin_convertvector(hi, f32x4), bf16x4_p);
+        *reinterpret_cast<bf16x4_p*>(pr + fn * 32) = hi;
+        *reinterpret_cast<bf16x4_p*>(pr + MC + fn * 32) = lo;
+      }
+    }
 #pragma unroll
     for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][fn][r] = 0.f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                    // staging reads done before the next pass refills the ring
-  }
+  };
+  auto issue_first = [&](int pass) {   // every wave is past the last slot hand-over of the pass before: no ring position is being read
+#pragma unroll
+    for (int d = 0; d < RING - 1; ++d)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) issue(g_qkv, 3 * C, pass * C, d, d, q);
+  };
+  // The stores issued between a pass's first slots and its hand-overs sit in the same counter as the weight copies.  The waits stay
+  // correct - loads complete in order among themselves, so "at most N operations outstanding" still implies "at most the last N copies
+  // outstanding" - they are only stricter until the stores have drained, which the epilogue's own instructions mostly cover.
+  gemm_pass(g_qkv, 3 * C, 0);                           // Q (its first slots were issued before the exchange)
+  issue_first(1);
+  // proj_in's output rows (the block's residual stream): here rather than in the exchange, whose stores the hand-overs of this pass
+  // would have waited for (the write burst of 256 workgroups in lockstep), and not later - they cost the V^T writer its registers
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) *reinterpret_cast<f32x4*>(e.y + (row0 + wave * RPW + i) * C + lane * 4) = v[i];
+  store_qk(0);
+  TRP();
+  gemm_pass(g_qkv, 3 * C, C);                           // K
+  issue_first(2);
+  store_qk(1);
+  TRP();
+  gemm_pass(g_qkv, 3 * C, 2 * C);                       // V: V^T [head][d][token] runs along the tokens - conv_epilogue's transposing
+  // writer, staged through the planes + ring regions (both idle now: 128 KB for its 69.6 KB)
+  conv_epilogue<1, BM, C, 1, 4, 2>(p, acc, b, 0, ox0, 2 * C, wm, wn, lane, tid, reinterpret_cast<float*>(sA));
+  TRP();
 #undef FRAGS_READY
 #undef SLOT_SYNC
 #undef IC
@@ -266,6 +338,9 @@ int launch_preattn_fused(const float* x, int batch, int l, float* sc, float* sh,
   p.ksplit = 1;
   p.tiles_x = l / 64; p.tiles_y = 1; p.nt = 1;
   conv_fill_divs(p);
+#ifdef PF_PRE_TRACE
+  if (const char* tp = getenv("PF_TRACE_PTR")) p.mean = reinterpret_cast<const float*>(strtoull(tp, nullptr, 16));
+#endif
   PreX e{static_cast<const __bf16*>(w_in), b_in, y, ln_gamma, ln_beta, ln_eps, static_cast<const __bf16*>(w_qkv)};
   constexpr size_t lds = 65536 + RING * 16384 + 8192;
   static_assert(lds <= 160 * 1024 && RING * 16384 + 8192 >= 256 * (64 + 4) * 4 && RING * 16384 + 8192 >= 64 * (256 + 8) * 4, "LDS budget / epilogue staging");

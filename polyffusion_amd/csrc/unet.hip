@@ -546,12 +546,13 @@ static bool mlp_fused_wanted(int C, int hw, int M, int force) {
 }
 
 // The fused pre-attention launch (preattn_fused_bf3.hip) has the feed-forward launch's shape - one four-wave workgroup per 64 tokens, a whole
-// CU each - and the same rule: used when the last round of CUs is at least 85 % full.  pf_unet_set_option(PF_OPT_PRE_FUSED) forces it off / on.
+// CU each.  Measured (profiles/r05_ab_pre_fused.md): 44 us per launch back to back at L = 1024, B = 16 against ~60 us for the three launches
+// it replaces inside the step, but end to end between -2 % and +0.7 % depending on the box (on one the part clocked 4 % lower with it in
+// the plan) - so AUTO keeps the three launches; pf_unet_set_option(PF_OPT_PRE_FUSED, PF_OPT_ON) turns it on (d_model 256, L % 64 == 0).
 static bool preattn_fused_wanted(int C, int hw, int M, int force) {
+  (void)M;
   if (C != 256 || hw % 64 != 0) return false;
-  if (force != PF_OPT_AUTO) return force != PF_OPT_OFF;
-  const int cus = num_cus(), tiles = M / 64, rounds = (tiles + cus - 1) / cus;
-  return tiles * 100 >= 85 * cus * rounds;
+  return force == PF_OPT_ON;
 }
 
 static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const float* cond, const float* cross_all) {

@@ -129,8 +129,8 @@ def test_preattn_fused_rejects_bad_arguments(lib):
 
 
 def test_unet_with_the_fused_pre_attention_launch_on_and_off():
-    """Whole sdf_chd8bar UNet at the bench shape (B = 16, bf16x3): the plan option changes the launch count by 2 per 32x32-level transformer
-    block and the result by summation-order rounding only; at B = 2 (tiles fill 3 % of the CUs) `auto` keeps the three launches."""
+    """Whole sdf_chd8bar UNet at the bench shape (B = 16, bf16x3): the plan option changes the launch count by 2 per transformer block and
+    the result by summation-order rounding only; `auto` keeps the three launches (the fused form measured neutral end to end)."""
     from polyffusion_amd.inference_sdf import synthetic_model
     from polyffusion_amd.params import preset
     m = synthetic_model(preset("sdf_chd8bar"))
@@ -149,10 +149,9 @@ def test_unet_with_the_fused_pre_attention_launch_on_and_off():
         u.set_option("pre_fused", True)
         n_on = u.n_launches(B)
         on = u(x, t, c).clone()
-        assert n_off - n_on == 2 * 11 and n_auto == n_off - 2 * 5      # forced: all 11 transformer blocks; auto at B = 16: the five 32x32-level ones
+        assert n_off - n_on == 2 * 11 and n_auto == n_off      # forced on: all 11 transformer blocks; auto = off
         assert (on - off).abs().max().item() <= 1e-4 and (base - off).abs().max().item() <= 1e-4
         u.set_option("pre_fused", None)
         assert torch.equal(u(x, t, c), base)
-        assert u.n_launches(2) == (u.set_option("pre_fused", False) or u).n_launches(2)
     finally:
         u.set_option("pre_fused", None)

@@ -11,6 +11,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 m = synthetic_model(preset("sdf_chd8bar"))
 u = m.ldm.eps_model
 u.set_precision(sys.argv[2] if len(sys.argv) > 2 else "bf16x3")
+for o in sys.argv[3:]:          # plan options, NAME=0|1
+    u.set_option(o.split("=")[0], bool(int(o.split("=")[1])))
 x = torch.from_numpy(synth.gaussian((B, 2, 128, 128), 1)).cuda()
 c = m._encode_chord(torch.from_numpy(synth.chords(B, 2)).cuda())
 t = torch.full((B,), 500, dtype=torch.long, device="cuda")
