@@ -125,6 +125,7 @@ def cpu_baseline(params, reps=3):
             "sample": f"median of {len(times)} single DDPM steps at batch {BATCH} (sdf_chd8bar) through oracle/unet_ref.py + sampler_ref.py "
                       f"after a warm-up step on the same inputs; {best} torch threads (best of the sweep) of {ncpu} host CPUs",
             "step_seconds": [round(t, 3) for t in times],
+            "spread_pct": round((times[-1] - times[0]) / med * 100, 1),
             "thread_sweep_steps_per_s": {str(n): round(1.0 / t, 4) for n, t in probes.items()}}
 
 
@@ -279,13 +280,38 @@ def profiled_pass(unet, step_fn, x, t_step, n_steps, precision, dump=False):
     return x, agg
 
 
-def small_batch_lines(model, params, steps, precision):
+def _median(vals):
+    v = sorted(vals)
+    return v[len(v) // 2]
+
+
+def windowed(run_window, windows: int, probe=None):
+    """`windows` back-to-back calls of run_window() (each a fixed number of steps, bracketed by synchronize + host clock inside this
+    helper, with the clock probe around it) -> (median seconds, all seconds, clock of the median window).  The protocol of the headline,
+    for the secondary lines."""
+    recs = []
+    for _ in range(max(1, windows)):
+        torch.cuda.synchronize()
+        if probe:
+            probe.begin()
+        t0 = time.perf_counter()
+        run_window()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        recs.append((dt, probe.end_mhz() if probe else None))
+    order = sorted(range(len(recs)), key=lambda i: recs[i][0])
+    med = recs[order[len(order) // 2]]
+    return med[0], [r[0] for r in recs], med[1]
+
+
+def small_batch_lines(model, params, steps, precision, windows=3, probe=None):
     """Secondary lines: the launch-bound regime.  Batch 1 is what the reference CLI's --autoreg runs (one 8-bar segment per
     sampling run), batch 8 the per-GPU shape of BASELINE config 5 (8 songs per GPU).  Each is timed through
-    SDFSampler.paint() - the RePaint loop body with orig/mask, exactly what Experiments.predict drives - once eagerly (about 220
-    host-side launches per step) and once as replays of one captured hipGraph step (device-resident step state)."""
-    import time as _t
+    SDFSampler.paint() - the RePaint loop body with orig/mask (first half known: the autoregressive overlap), exactly what
+    Experiments.predict drives - eagerly and as replays of one captured hipGraph step (device-resident step state); median of
+    `windows` paint() calls of `steps`+1 reverse steps each, with the fraction of the bf16x3 ceiling the denoiser reaches."""
     dev = torch.device("cuda", torch.cuda.current_device())
+    f_eval = F_MIN_PER_SAMPLE_EVAL - (F_UPFOLD_SAVED if precision == "bf16x3" else 0.0)
     res = {}
     for B in (1, 8):
         chords = torch.from_numpy(synth.chords(B, seed=777)).to(dev)
@@ -298,28 +324,31 @@ def small_batch_lines(model, params, steps, precision):
         for mode in ("eager", "graph"):
             s = SDFSampler(model.ldm, seed=3, graph=(mode == "graph"))
             x = s.randn(shape, dev)
-            s.paint(x, cond, 3, orig=z, mask=mask)                       # warm-up (tile instantiation, workspace)
-            torch.cuda.synchronize()
-            t0 = _t.perf_counter()
-            s.paint(x, cond, steps, orig=z, mask=mask)                   # steps+1 reverse steps
-            torch.cuda.synchronize()
-            wall = _t.perf_counter() - t0
-            line[mode + "_steps_per_s"] = round((steps + 1) / wall, 2)
+            s.paint(x, cond, 3, orig=z, mask=mask)                       # warm-up (tile instantiation, workspace, graph capture)
+            med, all_s, mhz = windowed(lambda: s.paint(x, cond, steps, orig=z, mask=mask), windows, probe)
+            line[mode + "_steps_per_s"] = round((steps + 1) / med, 2)
+            line[mode + "_ms_per_step"] = round(med / (steps + 1) * 1e3, 4)
+            line[mode + "_windows_ms_per_step"] = [round(t / (steps + 1) * 1e3, 4) for t in all_s]
+            line[mode + "_sclk_mhz"] = mhz
             if mode == "graph":
                 e0, e1, n = s.last_replay
                 line["graph_replay_ms_per_step"] = round(e0.elapsed_time(e1) / n, 4)
-                line["graph_note"] = "wall time includes capturing + instantiating the graph once per paint() call"
+        best = min(line["eager_ms_per_step"], line["graph_ms_per_step"])
+        line["roofline_frac"] = round(f_eval * B / (best * 1e-3) / (PEAK_ALGO[precision] * 1e12), 4)
+        line["roofline_note"] = "whole denoiser path: executed FLOPs per step / the faster of the two step times / the mode's matrix-pipe ceiling"
         res[f"batch{B}"] = line
     res["precision"] = precision
-    res["steps"] = steps + 1
+    res["steps_per_window"] = steps + 1
+    res["windows"] = windows
+    res["workload_batch8"] = ("BASELINE configs[4] per GPU: 8 songs denoised together, DDPM loop body with the first half of every image known "
+                              "(the autoregressive overlap of inference_sdf.py:227-283)")
     return res
 
 
-def config3_line(model, params, steps=10):
+def config3_line(model, params, steps=10, windows=3, probe=None):
     """BASELINE.json configs[2]: DDIM 50 steps, uncond_scale 5 (classifier-free guidance: every step evaluates 2 x 32 = 64 samples), batch 32.
-    Timed through DDIMSampler.paint (eager): `steps` reverse steps from tau index 49."""
+    Timed through DDIMSampler.p_sample (eager): windows of `steps` reverse steps from tau index 49, median window."""
     from polyffusion_amd.sampler import DDIMSampler
-    import time as _t
     dev = torch.device("cuda", torch.cuda.current_device())
     B = 32
     cond = model._encode_chord(torch.from_numpy(synth.chords(B, seed=888)).to(dev))
@@ -328,22 +357,73 @@ def config3_line(model, params, steps=10):
     shape = (B, params.out_channels, params.img_h, params.img_w)
     x = d.randn(shape, dev)
     prep = d.prepare(cond, uncond_scale=5.0, uncond_cond=uc)   # what DDIMSampler.paint hoists out of its loop
+    out = [x]
 
     def run(n):
         xx = x
         for i, step in enumerate(np.flip(d.time_steps)[:n]):
             xx, _, _ = d.p_sample(xx, cond, None, int(step), 49 - i, uncond_scale=5.0, uncond_cond=uc, prep=prep)
-        return xx
+        out[0] = xx
 
     run(2)
-    torch.cuda.synchronize()
-    t0 = _t.perf_counter()
-    out = run(steps)
-    torch.cuda.synchronize()
-    dt = _t.perf_counter() - t0
-    assert torch.isfinite(out).all()
-    return {"workload": "sdf_chd8bar DDIM 50-step, uncond_scale 5, batch 32 (64 UNet sample-evals per step), 1 GPU", "steps": steps,
-            "steps_per_s": round(steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3), "sample_evals_per_s": round(64 * steps / dt, 1)}
+    med, all_s, mhz = windowed(lambda: run(steps), windows, probe)
+    assert torch.isfinite(out[0]).all()
+    f_eval = F_MIN_PER_SAMPLE_EVAL - F_UPFOLD_SAVED
+    return {"workload": "sdf_chd8bar DDIM 50-step, uncond_scale 5, batch 32 (64 UNet sample-evals per step), 1 GPU", "steps": steps, "windows": windows,
+            "steps_per_s": round(steps / med, 3), "ms_per_step": round(med / steps * 1e3, 3), "sample_evals_per_s": round(64 * steps / med, 1),
+            "windows_ms_per_step": [round(t / steps * 1e3, 3) for t in all_s], "sclk_mhz": mhz,
+            "roofline_frac": round(f_eval * 64 * steps / med / (PEAK_ALGO["bf16x3"] * 1e12), 4)}
+
+
+def config4_line(steps=20, windows=3, probe=None):
+    """The per-GPU shape of BASELINE.json configs[3]: sdf_txt (texture condition through the HIP texture encoder, d_cond 1024), batch 16
+    (128 samples sharded over 8 GPUs), DDPM loop body - the headline's step with the other conditioning width."""
+    from polyffusion_amd.inference_sdf import synthetic_model
+    dev = torch.device("cuda", torch.cuda.current_device())
+    p = preset("sdf_txt")
+    m = synthetic_model(p)
+    m.ldm.eps_model.set_precision("bf16x3")
+    cond = m._encode_txt(torch.from_numpy(synth.prmat(BATCH, 32)).to(dev))
+    s = SDFSampler(m.ldm, seed=11)
+    shape = (BATCH, p.out_channels, p.img_h, p.img_w)
+    z = torch.zeros(shape, device=dev)
+    st = {"x": s.q_sample(z, p.n_steps - 1, s.randn(shape, dev)), "t": p.n_steps - 1}
+    prep = s.prepare(cond)
+
+    def run(n):
+        for _ in range(n):
+            st["x"] = s.repaint_step(st["x"], cond, st["t"], z, z, prep=prep)
+            st["t"] = max(st["t"] - 1, 1)
+
+    run(3)
+    med, all_s, mhz = windowed(lambda: run(steps), windows, probe)
+    assert torch.isfinite(st["x"]).all()
+    return {"workload": "sdf_txt (d_cond 1024, HIP texture encoder) batch 16 per GPU, DDPM loop body: BASELINE configs[3] per GPU", "steps": steps,
+            "windows": windows, "steps_per_s": round(steps / med, 3), "ms_per_step": round(med / steps * 1e3, 4),
+            "windows_ms_per_step": [round(t / steps * 1e3, 4) for t in all_s], "sclk_mhz": mhz, "cond_shape": list(cond.shape)}
+
+
+def long_parity_note(model, measure: bool):
+    """The three full-length f32-vs-bf16x3 comparisons (tools/long_parity.py; tests/test_gpu_long_parity.py asserts their bounds).  Config 3
+    (50 DDIM steps, guidance 5, B = 32: ~4 s) is re-measured in this run when `measure`; the two 1000-step ones (19 s and 37 s) are quoted from
+    the committed record of the same code path, profiles/r05_long_parity.json."""
+    keep = lambda r: {"final_max_abs": r["max_abs"], "final_rms": r["rms"], "image_rms": r["ref_rms"], "image_max_abs": r["ref_max_abs"],
+                      "notes": r["notes"], "curve_max_abs_last": r["curve_max_abs"][-1][2], "what": r["what"]}
+    out = {}
+    path = os.path.join(REPO, "profiles", "r05_long_parity.json")
+    rec = json.load(open(path)) if os.path.exists(path) else {}
+    for k in ("config2", "config5"):
+        if k in rec:
+            out[k] = dict(keep(rec[k]), source="profiles/r05_long_parity.json")
+    if measure:
+        try:
+            from tools import long_parity
+            out["config3"] = dict(keep(long_parity.config3(model)), source="measured in this run")
+        except Exception as e:   # never lose the bench line to a diagnostic
+            out["config3_error"] = f"{type(e).__name__}: {e}"
+    if "config3" not in out and "config3" in rec:
+        out["config3"] = dict(keep(rec["config3"]), source="profiles/r05_long_parity.json")
+    return out
 
 
 def main():
@@ -357,6 +437,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the two rocprofv3 counter passes that measure roofline.traffic in the run")
     ap.add_argument("--small-batch-steps", type=int, default=40, help="reverse steps of the batch-1 / batch-8 eager-vs-hipGraph lines (0 disables)")
+    ap.add_argument("--secondary-windows", type=int, default=3, help="timed windows of every secondary line (fp32 mode, small batch, configs 3 / 4); median reported")
+    ap.add_argument("--no-long-parity", action="store_true", help="do not re-measure the 50-step DDIM f32-vs-bf16x3 comparison for precision_note")
     ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="arithmetic of the dense contractions: exact fp32 MFMA, or the error-compensated bf16x3 split")
     ap.add_argument("--dump-launches", action="store_true", help="print one line per kernel launch of a profiled step (stderr)")
@@ -419,6 +501,8 @@ def main():
     elapsed, ev_elapsed, med_mhz = wins[order[len(order) // 2]]
 
     ms_per_step = elapsed / args.steps * 1e3
+    # this rank's own clock over the median window's steps (events on its launch stream): a straggler shows as max >> min
+    rank_ms = pfdist.gather_floats(ev_elapsed / args.steps * 1e3)
     # work actually executed (never count skipped work): the bf16x3 plan folds nearest-x2 + conv3x3 into four 2x2 convs
     f_eval = F_MIN_PER_SAMPLE_EVAL - (F_UPFOLD_SAVED if args.precision == "bf16x3" else 0.0)
     value = world * args.steps / elapsed
@@ -431,6 +515,8 @@ def main():
                    "global_batch": BATCH * world, "unet_evals_per_step": BATCH * world, "parallelism": f"batch-shard x{world}",
                    "weight_broadcast_s": round(bcast_s, 4), "launches_per_step": unet.n_launches(BATCH, prepared=True) + 1},
         "ms_per_step_hip_events": round(ev_elapsed / args.steps * 1e3, 4),
+        "per_rank_ms_per_step": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4), "all": [round(v, 4) for v in rank_ms],
+                                 "how": "each rank's HIP-event time over the median window's steps on its own stream (no barrier inside)"},
         "windows": len(wins), "windows_ms_per_step": [round(w[0] / args.steps * 1e3, 4) for w in wins],
         "windows_spread_pct": round((max(w[0] for w in wins) - min(w[0] for w in wins)) / elapsed * 100, 2),
         "window_rule": "value / ms_per_step = the MEDIAN of the windows (each exactly --steps steps between barrier + synchronize pairs)",
@@ -503,13 +589,19 @@ def main():
         out["kernel_ms_per_step_corrected"]["sum"] = round(sum(out["kernel_ms_per_step_corrected"].values()), 4)
 
     if args.fp32_steps > 0 and args.precision == "bf16x3":
-        # the exact-fp32-MFMA mode in the same run, same workload (every rank runs it so the barriers line up)
+        # the exact-fp32-MFMA mode in the same run, same workload, the headline's protocol (every rank runs it so the barriers line up)
         unet.set_precision("f32")
         for _ in range(2):
             x = step_fn(x, t_step)
-        x, t_step, el32, _, mhz32 = timed_loop(step_fn, x, t_step, args.fp32_steps, probe)
+        w32 = []
+        for _ in range(max(1, args.secondary_windows)):
+            x, t_step, el32, _, mhz32 = timed_loop(step_fn, x, t_step, args.fp32_steps, probe)
+            w32.append((el32, mhz32))
+        o32 = sorted(range(len(w32)), key=lambda i: w32[i][0])
+        el32, mhz32 = w32[o32[len(o32) // 2]]
         fp32 = {"steps_per_s": round(world * args.fp32_steps / el32, 4), "ms_per_step": round(el32 / args.fp32_steps * 1e3, 4),
-                "steps": args.fp32_steps, "sclk_mhz": mhz32,
+                "steps": args.fp32_steps, "windows": len(w32), "windows_ms_per_step": [round(w[0] / args.fp32_steps * 1e3, 4) for w in w32],
+                "sclk_mhz": mhz32,
                 "path_frac_of_157": round(F_MIN_PER_SAMPLE_EVAL * BATCH * args.fp32_steps / el32 / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)}
         if rank == 0 and args.profile_steps > 0:
             x, agg32 = profiled_pass(unet, step_fn, x, t_step, 1, "f32")
@@ -518,8 +610,18 @@ def main():
         unet.set_precision(args.precision)
         out["fp32_mode"] = fp32
     if rank == 0 and args.small_batch_steps > 0:
-        out["small_batch"] = small_batch_lines(model, params, args.small_batch_steps, args.precision)
-        out["config3"] = config3_line(model, params)
+        out["small_batch"] = small_batch_lines(model, params, args.small_batch_steps, args.precision, args.secondary_windows, probe)
+        out["config3"] = config3_line(model, params, 10, args.secondary_windows, probe)
+        if world == 1:
+            out["config4_shape"] = config4_line(20, args.secondary_windows, probe)
+    if rank == 0 and args.precision == "bf16x3":
+        out["long_parity"] = long_parity_note(model, measure=(world == 1 and not args.no_long_parity and args.small_batch_steps > 0))
+        lp = out["long_parity"]
+        if all(k in lp for k in ("config2", "config3", "config5")):
+            out["precision_note"] += ("; full-length loops f32 vs bf16x3 on one noise tape (final max-abs-diff / differing note cells): "
+                                      + ", ".join(f"{k} {lp[k]['final_max_abs']:.1e} of images at rms {lp[k]['image_rms']:.0f} / "
+                                                  f"{lp[k]['notes']['onset_bits_differ'] + lp[k]['notes']['sustain_bits_differ']} of {2 * lp[k]['notes']['cells']}"
+                                                  for k in ("config2", "config3", "config5")))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params)
     if rank == 0:

@@ -126,6 +126,17 @@ def broadcast_int(value: int, src: int = 0) -> int:
     return int(value)
 
 
+def gather_floats(value: float) -> list:
+    """Every rank's value, in rank order, on every rank (a one-element list in single-process runs).  One all_reduce of a vector
+    that is zero except at the caller's own rank: works on every backend the other helpers here work on."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.zeros(dist.get_world_size(), dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+        t[dist.get_rank()] = float(value)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+    return [float(value)]
+
+
 def gather_rows(local: torch.Tensor, total: int, rank: int, world: int) -> torch.Tensor:
     """Concatenate the ranks' row blocks (rank r holds rows ``shard_range(total, r, world)``) on every rank.
 

@@ -166,7 +166,7 @@ def test_shard_plan_world_size_2_gloo(tmp_path):
     script.write_text(f'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, {REPO!r})
-from polyffusion_amd.dist import shard_range, broadcast_blob, gather_rows, broadcast_int, ranks_seen
+from polyffusion_amd.dist import shard_range, broadcast_blob, gather_rows, gather_floats, broadcast_int, ranks_seen
 dist.init_process_group("gloo")
 r, n = dist.get_rank(), dist.get_world_size()
 lo, hi = shard_range(37, r, n)
@@ -183,6 +183,7 @@ allrows = gather_rows(rows, 5, r, n)
 assert allrows.shape == (5, 2, 3) and torch.equal(allrows[:, 0, 0], torch.arange(5.)), allrows
 assert gather_rows(torch.zeros(0, 4) if r == 1 else torch.ones(1, 4), 1, r, n).shape == (1, 4)   # a rank with no rows
 assert broadcast_int(1234 + r) == 1234
+assert gather_floats(1.5 + r) == [1.5 + i for i in range(n)]     # bench.py's per-rank step times
 assert ranks_seen()[0] == n
 dist.barrier()
 if r == 0: print("OK", got)
