@@ -915,11 +915,12 @@ static int dispatch_tile3(ConvP& p, int tile, hipStream_t s) {
       // no more tiles than CUs (and an even number of K chunks): two wave groups per workgroup split K (see the kernel)
       const int blocks = p.B * cdiv(p.Hout, tile == 3 ? 16 : tile == 2 ? 4 : 8) * cdiv(p.Wout, 16) * cdiv(p.Npad, tile == 0 ? 128 : 64);
       // (the 128x128 tile split the same way measured neutral - its two wave groups run in lockstep behind the shared barrier - DESIGN.md 3)
-      const bool kg2 = tile == 2 && p.ksplit == 1 && blocks <= 256 && ((p.c0 + p.c1) / 32) % 2 == 0 && (!p.sw || ((p.sc0 + p.sc1) / 32) % 2 == 0);
+      const int cus = num_cus();
+      const bool kg2 = tile == 2 && p.ksplit == 1 && blocks <= cus && ((p.c0 + p.c1) / 32) % 2 == 0 && (!p.sw || ((p.sc0 + p.sc1) / 32) % 2 == 0);
       if (kg2) return p.sw ? launch3_cfg<3, 1, false, 4, 16, 64, 1, 2, true, 2>(p, s) : launch3_cfg<3, 1, false, 4, 16, 64, 1, 2, false, 2>(p, s);
       // ... but run as two groups half a tap apart (conv_bf3_pingpong) it gains: one group's fragment reads / copies / halo arithmetic
       // hide behind the other's MFMAs (B = 16: the 32x32 level; B = 8: the 64x64 level)
-      if (p.pp && tile == 0 && p.ksplit == 1 && blocks <= 256 && ((p.c0 + p.c1) / 32) % 2 == 0 && (!p.sw || ((p.sc0 + p.sc1) / 32) % 2 == 0))
+      if (p.pp && tile == 0 && p.ksplit == 1 && blocks <= cus && ((p.c0 + p.c1) / 32) % 2 == 0 && (!p.sw || ((p.sc0 + p.sc1) / 32) % 2 == 0))
         return p.sw ? launch3_cfg<3, 1, false, 8, 16, 128, 1, 2, true, 2>(p, s) : launch3_cfg<3, 1, false, 8, 16, 128, 1, 2, false, 2>(p, s);
       if (tile == 3) return p.sw ? launch3_cfg<3, 1, false, 16, 16, 64, 1, 2, true>(p, s) : launch3_cfg<3, 1, false, 16, 16, 64, 1, 2, false>(p, s);
       if (p.sw) {   // fused skip projection: only the ResBlock second-conv configurations are instantiated

@@ -246,12 +246,13 @@ int conv_pick_tile(const pf_conv_args& a) {
   // bf16x3 3x3 with 64 output channels in all (the 128x128 level): a 16x16-pixel tile when that still gives every CU two rounds of
   // two workgroups - each wave then owns 128 pixels x 32 channels (four A fragments per weight fragment instead of two)
   if (a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.stride == 1 && !a.ups && !a.ups_fold && npad == 64 && hout % 16 == 0 && wout % 16 == 0 &&
-      a.batch * (hout / 16) * (wout / 16) >= 1024 && !a.skip_w && a.c0 + a.c1 >= 128 && !a.no_t16) return 3;
+      a.batch * (hout / 16) * (wout / 16) >= 4 * num_cus() && !a.skip_w && a.c0 + a.c1 >= 128 && !a.no_t16) return 3;
   // (the same 16x16-pixel footprint for the 128-channel tile - 128 x 64 per wave, one workgroup per CU - measured worse at the 64x64
   // level: r64_128_128 55.3 -> 57 us, the fused-skip form 79 -> 82, only the K = 3456 conv gained 2.5 %)
   const bool wide_at_256 = a.precision == PF_PREC_BF16X3 && (a.ks == 3 || a.a_planes);
-  if (npad % 128 == 0 && mt128 * (npad / 128) >= (wide_at_256 ? 256 : 512)) return 0;
-  if (mt128 * (npad / 64) >= 512) return 1;
+  const int cus = num_cus();   // (the thresholds were measured on 256 CUs; they are rounds of the chip, not literals)
+  if (npad % 128 == 0 && mt128 * (npad / 128) >= (wide_at_256 ? cus : 2 * cus)) return 0;
+  if (mt128 * (npad / 64) >= 2 * cus) return 1;
   return 2;
 }
 void conv_tile_shape(const pf_conv_args& a, int tile, int* th, int* tw) {
@@ -269,9 +270,9 @@ static int ksplit_wanted(const pf_conv_args& a) {
   conv_tile_shape(a, conv_pick_tile(a), &th, &tw);
   const int blocks = a.batch * cdiv(hout, th) * cdiv(wout, tw) * cdiv((a.n + 63) / 64 * 64, 64);
   const int nchunk = (a.c0 + a.c1) / 32;
-  if (blocks >= 256) return 1;   // one workgroup per CU already: measured, splitting further only adds the reduce pass
+  if (blocks >= num_cus()) return 1;   // one workgroup per CU already: measured, splitting further only adds the reduce pass
   int s = 1;
-  while (s < 4 && blocks * s * 2 <= 1024 && nchunk % (s * 2) == 0) s *= 2;
+  while (s < 4 && blocks * s * 2 <= 4 * num_cus() && nchunk % (s * 2) == 0) s *= 2;
   return s;
 }
 size_t conv_splitk_ws_bytes(const pf_conv_args& a) {

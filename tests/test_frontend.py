@@ -96,3 +96,91 @@ def test_midi_round_trip_through_the_front_end(tmp_path):
     assert np.array_equal(p2c.numpy(), want)
     assert np.array_equal((prmat.numpy() > 0), want[:, 0] > 0)
     assert chd.sum(-1).min() >= 2.0                              # every beat carries a root and a bass (N rows have root -1 -> last one-hot slot)
+
+
+def test_reference_example_mid_round_trips_through_the_writer(tmp_path):
+    """The reference's own MIDI file (chord_extractor/example.mid: 12 instrument tracks, 384 ticks per beat, 4/4) through the front end,
+    out through the product's writer (one track, 220 ticks per beat, 120 bpm) and in again: the de-duplicated note matrix (onset, pitch,
+    duration at 4 bins per beat), the barlines, their filter and the start table are identical - resolution change, FIFO note pairing,
+    de-duplication and barline inference are consistent between two very different encodings of the same music.  (A property of THIS
+    restatement; the muspy-side parity stays unpinned, see the module header.)"""
+    src = os.path.join(GOLD, "chord_example.mid")
+    a = midi_to_data.Music(src)
+    a.adjust_resolution(midi_to_data.BIN)
+    na = midi_to_data.dedup_note_matrix(midi_to_data.get_note_matrix(a))
+    db_a, flt_a = midi_to_data.get_downbeat_pos_and_filter(a)
+    assert len(na) == 3890 and db_a[:3] == [0, 16, 32] and len(db_a) == 91
+    # a bin is a 16th note = 1/8 s at the writer's 120 bpm
+    path = str(tmp_path / "rt.mid")
+    # one written track per source program: notes of different instruments that overlap on one pitch must not share a channel (a note-off
+    # closes the oldest open note of its channel and pitch - FIFO - so merging instruments would re-pair them)
+    progs = sorted({n[4] for n in na})
+    midi.write_smf(path, [[(n[1], n[0] / 8.0, (n[0] + n[2]) / 8.0) for n in na if n[4] == pg] for pg in progs])
+    b = midi_to_data.Music(path)
+    assert b.resolution == midi.RESOLUTION and len(b.tracks) == len(progs)
+    b.adjust_resolution(midi_to_data.BIN)
+    nb = midi_to_data.dedup_note_matrix(midi_to_data.get_note_matrix(b))
+    assert [n[:3] for n in nb] == [n[:3] for n in na]
+    db_b, flt_b = midi_to_data.get_downbeat_pos_and_filter(b)
+    # the written file ends with its last note; the source's end time also counts a tempo event: compare the bars both cover
+    k = min(len(db_a), len(db_b))
+    assert k >= 90 and db_a[:k] == db_b[:k] and flt_a[:k - 1] == flt_b[:k - 1]
+    assert midi_to_data.get_start_table(na, db_a[:k]) == midi_to_data.get_start_table(nb, db_b[:k])
+
+
+def _smf(path, division, events):
+    """A one-track format-0 file from (tick, bytes) events."""
+    body, last = b"", 0
+    for tick, raw in sorted(events, key=lambda e: e[0]):
+        body += midi._vlq(tick - last) + raw
+        last = tick
+    body += b"\x00\xff\x2f\x00"
+    import struct
+    with open(path, "wb") as f:
+        f.write(b"MThd" + struct.pack(">IHHH", 6, 0, 1, division) + b"MTrk" + struct.pack(">I", len(body)) + body)
+
+
+def test_front_end_on_the_four_risk_cases(tmp_path):
+    """Hand-made files for the four cases ADVICE r3 named.  What is asserted is what THIS restatement does, derived by hand from the rules
+    in the module header (events in file order, FIFO pairing, barlines from each time signature to the next) - not muspy output: muspy 0.5.0
+    is not in the image and the reference holds no fixture, so these pin the restatement against regressions and document its choices."""
+    on = lambda ch, p, v=80: bytes([0x90 | ch, p, v])
+    off = lambda ch, p: bytes([0x80 | ch, p, 0])
+    ts = lambda n, dpow: b"\xff\x58\x04" + bytes([n, dpow, 24, 8])
+    tempo = b"\xff\x51\x03\x07\xa1\x20"
+    q = 96                                       # ticks per quarter -> a 16th-note bin is 24 ticks
+    # (1) the first time signature arrives at t > 0 (bar 2): barlines start THERE - nothing is assumed before it, so notes ahead of it
+    # sit before the first downbeat and the start table's first entry skips them
+    p1 = str(tmp_path / "late_ts.mid")
+    _smf(p1, q, [(0, on(0, 60)), (q, off(0, 60)), (4 * q, ts(4, 2)), (4 * q, on(0, 62)), (6 * q, off(0, 62)), (12 * q, on(0, 64)), (13 * q, off(0, 64))])
+    m1 = midi_to_data.Music(p1); m1.adjust_resolution(4)
+    assert m1.time_signatures == [[16, 4, 4]]
+    n1 = midi_to_data.dedup_note_matrix(midi_to_data.get_note_matrix(m1))
+    assert [n[:3] for n in n1] == [[0, 60, 4], [16, 62, 8], [48, 64, 4]]
+    db1, f1 = midi_to_data.get_downbeat_pos_and_filter(m1)
+    assert db1 == [16, 32, 48] and midi_to_data.get_start_table(n1, db1) == {16: 1, 32: 2, 48: 2}
+    # (2) the same time signature repeated (at the same tick and one bar later): every event is kept in file order; a repeat at the same
+    # tick contributes an empty span, a later repeat just restarts the same grid - the barlines are those of a single 3/4 signature
+    p2 = str(tmp_path / "dup_ts.mid")
+    _smf(p2, q, [(0, ts(3, 2)), (0, ts(3, 2)), (3 * q, ts(3, 2)), (0, on(0, 60)), (9 * q, off(0, 60))])
+    m2 = midi_to_data.Music(p2); m2.adjust_resolution(4)
+    assert m2.time_signatures == [[0, 3, 4], [0, 3, 4], [12, 3, 4]]
+    db2, f2 = midi_to_data.get_downbeat_pos_and_filter(m2)
+    assert db2 == [0, 12, 24] and f2 == [False, False, False]          # 3-beat bars are never usable (the reference keeps 2 / 4 / 8 beats)
+    # (3) no time signature at all, tempo events only: get_data_for_single_midi supplies 4/4 at 0 (midi_to_data.py:226-227 of the reference
+    # appends TimeSignature(0, 4, 4)), and the tempo event's time counts towards the end time like any other
+    p3 = str(tmp_path / "tempo_only.mid")
+    _smf(p3, q, [(0, tempo), (0, on(0, 60)), (2 * q, off(0, 60)), (16 * q, tempo)])
+    m3 = midi_to_data.Music(p3); m3.adjust_resolution(4)
+    assert m3.time_signatures == [] and m3.get_end_time() == 64
+    m3.time_signatures.append([0, 4, 4])
+    db3, f3 = midi_to_data.get_downbeat_pos_and_filter(m3)
+    assert db3 == [0, 16, 32, 48] and f3 == [True, True, True, True]
+    # (4) a note-off without a note-on, a second note-on before the first note-off (FIFO: the first off closes the FIRST on), and a
+    # note-on that is never closed (dropped): no exception, no phantom note
+    p4 = str(tmp_path / "dangling.mid")
+    _smf(p4, q, [(0, ts(4, 2)), (0, off(0, 70)), (0, on(0, 60)), (q, on(0, 60)), (2 * q, off(0, 60)), (4 * q, off(0, 60)), (5 * q, on(0, 72))])
+    m4 = midi_to_data.Music(p4); m4.adjust_resolution(4)
+    n4 = midi_to_data.get_note_matrix(m4)
+    assert [n[:3] for n in n4] == [[0, 60, 8], [4, 60, 12]]
+    assert [n[:3] for n in midi_to_data.dedup_note_matrix(n4)] == [[0, 60, 8], [4, 60, 12]]
