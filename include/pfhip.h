@@ -330,6 +330,10 @@ typedef struct pf_conv_args {
   const int64_t* sbias_rows; int32_t sbias_nrows;
   int32_t no_t16;          /* != 0: never pick the 16x16-pixel tile (PF_OPT_CONV_T16 = off) */
   int32_t no_pp;           /* != 0: never run the two-group ping-pong form of the 128-wide tile (PF_OPT_CONV_PP = off) */
+  /* measurement aids (tools/sweep_conv.py): 0 = the library's own choice.  force_tile: 1 + tile index (1: 128 px x 128 ch, 2: 128 px x 64 ch,
+   * 3: 64 px x 64 ch; bf16x3 3x3 stride 1 only, tile 1 needs n %% 128 == 0); force_ksplit: K slices across workgroups (bf16x3 3x3 stride 1,
+   * must divide the 32-channel chunks; > 1 needs splitk_ws).  Results are the same up to summation order. */
+  int32_t force_tile, force_ksplit;
 } pf_conv_args;
 /* scratch bytes a launch with these arguments would like for split-K (0 = the launch does not split) */
 size_t pf_conv_splitk_ws_bytes(const pf_conv_args* a);

@@ -66,6 +66,7 @@ class ConvArgs(C.Structure):
         ("gn_stats0", C.c_void_p), ("gn_tiles0", C.c_int32), ("gn_stats1", C.c_void_p), ("gn_tiles1", C.c_int32),
         ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float), ("gn_groups", C.c_int32),
         ("sbias_rows", C.c_void_p), ("sbias_nrows", C.c_int32), ("no_t16", C.c_int32), ("no_pp", C.c_int32),
+        ("force_tile", C.c_int32), ("force_ksplit", C.c_int32),
     ]
 
 

@@ -920,7 +920,8 @@ static int dispatch_tile3(ConvP& p, int tile, hipStream_t s) {
       if (kg2) return p.sw ? launch3_cfg<3, 1, false, 4, 16, 64, 1, 2, true, 2>(p, s) : launch3_cfg<3, 1, false, 4, 16, 64, 1, 2, false, 2>(p, s);
       // ... but run as two groups half a tap apart (conv_bf3_pingpong) it gains: one group's fragment reads / copies / halo arithmetic
       // hide behind the other's MFMAs (B = 16: the 32x32 level; B = 8: the 64x64 level)
-      if (p.pp && tile == 0 && p.ksplit == 1 && blocks <= cus && ((p.c0 + p.c1) / 32) % 2 == 0 && (!p.sw || ((p.sc0 + p.sc1) / 32) % 2 == 0))
+      // (from K = 2304 up: at K = 576 ... 1728 the two-group form measured 3-6 % behind the four-wave one - r32_128_256, r64_128_128 at B = 8)
+      if (p.pp && tile == 0 && p.ksplit == 1 && blocks <= cus && (p.c0 + p.c1) >= 256 && ((p.c0 + p.c1) / 32) % 2 == 0 && (!p.sw || ((p.sc0 + p.sc1) / 32) % 2 == 0))
         return p.sw ? launch3_cfg<3, 1, false, 8, 16, 128, 1, 2, true, 2>(p, s) : launch3_cfg<3, 1, false, 8, 16, 128, 1, 2, false, 2>(p, s);
       if (tile == 3) return p.sw ? launch3_cfg<3, 1, false, 16, 16, 64, 1, 2, true>(p, s) : launch3_cfg<3, 1, false, 16, 16, 64, 1, 2, false>(p, s);
       if (p.sw) {   // fused skip projection: only the ResBlock second-conv configurations are instantiated

@@ -241,6 +241,8 @@ int conv_pick_tile(const pf_conv_args& a) {
   const int npad = (a.n + 63) / 64 * 64;
   const int mt128 = a.ks == 1 ? a.batch * hout * cdiv(wout, 128) : a.batch * cdiv(hout, 8) * cdiv(wout, 16);
   if (a.ks == 3 && a.stride == 2) return 2;
+  if (a.force_tile >= 1 && a.force_tile <= 3 && a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.stride == 1 && !a.ups && !a.ups_fold &&
+      (a.force_tile != 1 || npad % 128 == 0)) return a.force_tile - 1;   // measurement aid (pf_conv_args.force_tile)
   // bf16x3 3x3: the wide tile + split-K beats twice as many narrow tiles; planes GEMMs (both operands direct-to-LDS): one 128x128 workgroup
   // per CU beats two 128x64 ones as soon as every CU gets one (measured at M = 16384, N = 256: K = 256 18.1 -> 16.1 us, K = 1024 37.5 -> 33.9 us)
   // bf16x3 3x3 with 64 output channels in all (the 128x128 level): a 16x16-pixel tile when that still gives every CU two rounds of
@@ -252,7 +254,10 @@ int conv_pick_tile(const pf_conv_args& a) {
   const bool wide_at_256 = a.precision == PF_PREC_BF16X3 && (a.ks == 3 || a.a_planes);
   const int cus = num_cus();   // (the thresholds were measured on 256 CUs; they are rounds of the chip, not literals)
   if (npad % 128 == 0 && mt128 * (npad / 128) >= (wide_at_256 ? cus : 2 * cus)) return 0;
-  if (mt128 * (npad / 64) >= 2 * cus) return 1;
+  // bf16x3 3x3: the 128 px x 64 ch tile as soon as it gives every CU a workgroup - at B = 8 the 32x32 level has exactly 256 of them and they
+  // beat 512 narrow tiles by 6-10 % (tools/sweep_conv.py, profiles/r05_sweep_conv_before.log); below that the 64 px tile fills more CUs
+  const bool bf3x3 = a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.stride == 1 && !a.ups;
+  if (mt128 * (npad / 64) >= (bf3x3 ? cus : 2 * cus)) return 1;
   return 2;
 }
 void conv_tile_shape(const pf_conv_args& a, int tile, int* th, int* tw) {
@@ -270,10 +275,14 @@ static int ksplit_wanted(const pf_conv_args& a) {
   conv_tile_shape(a, conv_pick_tile(a), &th, &tw);
   const int blocks = a.batch * cdiv(hout, th) * cdiv(wout, tw) * cdiv((a.n + 63) / 64 * 64, 64);
   const int nchunk = (a.c0 + a.c1) / 32;
-  if (blocks >= num_cus()) return 1;   // one workgroup per CU already: measured, splitting further only adds the reduce pass
-  int s = 1;
-  while (s < 4 && blocks * s * 2 <= 4 * num_cus() && nchunk % (s * 2) == 0) s *= 2;
-  return s;
+  if (a.force_ksplit >= 1 && nchunk % a.force_ksplit == 0) return a.force_ksplit;   // measurement aid (pf_conv_args.force_ksplit)
+  // Round 5, from a sweep of every layer shape at B = 1 / 8 / 16 (tools/sweep_conv.py, profiles/r05_sweep_conv_before.log): the split pays
+  // only for DEEP K on FEW workgroups - its fp32 partial sums and the reduce launch cost ~8 us, which a K = 2304 loop (25 us unsplit on
+  // any number of workgroups, 17 us with the intra-workgroup split) never earns back: B = 8, 16x16 level 22.9 -> 17.4 us, B = 1, 64x64
+  // level 19.5 -> 11.5 us without it.  K >= 4608 on at most half the CUs, or K >= 3456 on at most a quarter: four slices (+10 ... +30 %).
+  const int cus = num_cus();
+  if (nchunk % 4 == 0 && ((nchunk >= 16 && blocks <= cus / 2) || (nchunk >= 12 && blocks <= cus / 4))) return 4;
+  return 1;
 }
 size_t conv_splitk_ws_bytes(const pf_conv_args& a) {
   const int s = ksplit_wanted(a);

@@ -133,9 +133,11 @@ def test_small_unet_bf16x3_vs_reference_golden(golden):
     assert np.abs(m(x, t, torch.from_numpy(g["cond4"]).cuda()).cpu().numpy() - g["out4"]).max() < 5e-4
 
 
-@pytest.mark.parametrize("B,H,W,c0,c1,cout", [(2, 16, 16, 256, 256, 256), (1, 8, 8, 64, 0, 64), (4, 16, 16, 256, 0, 256)])
-def test_split_k_small_m_layers(lib, B, H, W, c0, c1, cout):
-    """Small-M 3x3 layers split K over workgroups; the reduce kernel applies bias/sbias/residual and emits the statistics."""
+@pytest.mark.parametrize("B,H,W,c0,c1,cout,fk", [(2, 16, 16, 256, 256, 256, 0), (1, 8, 8, 64, 0, 64, 2), (4, 16, 16, 256, 0, 256, 4), (1, 32, 32, 256, 128, 256, 0)])
+def test_split_k_small_m_layers(lib, B, H, W, c0, c1, cout, fk):
+    """Small-M 3x3 layers split K over workgroups; the reduce kernel applies bias/sbias/residual and emits the statistics.  fk == 0: the
+    library's own choice (deep K on few workgroups - the only case where the split earns its reduce pass, tools/sweep_conv.py); fk > 0: the
+    split forced (pf_conv_args.force_ksplit) on shapes the picker now leaves whole."""
     cin = c0 + c1
     x = rnd((B, cin, H, W), 1) * 1.5 + 0.3
     w, bias = rnd((cout, cin, 3, 3), 2, (1.0 / (cin * 9)) ** 0.5), rnd((cout,), 3, 0.1)
@@ -146,7 +148,7 @@ def test_split_k_small_m_layers(lib, B, H, W, c0, c1, cout):
     x1 = dev(nhwc(x[:, c0:])) if c1 else None
     sc, sh = gn_scale_shift(lib, x0, x1, dev(gamma), dev(beta), 1e-5)
     kw = dict(x0=x0, c0=c0, x1=x1, c1=c1, batch=B, hin=H, win=W, ks=3, stride=1, ups=0, w=pack3(lib, w), n=cout,
-              prologue=1, sc=sc, sh=sh, bias=dev(bias), sbias=dev(sb), ld_sbias=cout, res=dev(nhwc(res)), ld_res=cout, precision=1)
+              prologue=1, sc=sc, sh=sh, bias=dev(bias), sbias=dev(sb), ld_sbias=cout, res=dev(nhwc(res)), ld_res=cout, precision=1, force_ksplit=fk)
     a = _lib.ConvArgs()
     for k, v in kw.items():
         setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
