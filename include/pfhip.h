@@ -331,7 +331,7 @@ typedef struct pf_conv_args {
   int32_t no_t16;          /* != 0: never pick the 16x16-pixel tile (PF_OPT_CONV_T16 = off) */
   int32_t no_pp;           /* != 0: never run the two-group ping-pong form of the 128-wide tile (PF_OPT_CONV_PP = off) */
   /* measurement aids (tools/sweep_conv.py): 0 = the library's own choice.  force_tile: 1 + tile index (1: 128 px x 128 ch, 2: 128 px x 64 ch,
-   * 3: 64 px x 64 ch; bf16x3 3x3 stride 1 only, tile 1 needs n %% 128 == 0); force_ksplit: K slices across workgroups (bf16x3 3x3 stride 1,
+   * 3: 64 px x 64 ch; bf16x3 3x3 stride 1 and planes GEMMs without GeGLU, tile 1 needs n %% 128 == 0); force_ksplit: K slices across workgroups (bf16x3 3x3 stride 1,
    * must divide the 32-channel chunks; > 1 needs splitk_ws).  Results are the same up to summation order. */
   int32_t force_tile, force_ksplit;
 } pf_conv_args;

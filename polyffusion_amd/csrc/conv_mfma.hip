@@ -241,8 +241,8 @@ int conv_pick_tile(const pf_conv_args& a) {
   const int npad = (a.n + 63) / 64 * 64;
   const int mt128 = a.ks == 1 ? a.batch * hout * cdiv(wout, 128) : a.batch * cdiv(hout, 8) * cdiv(wout, 16);
   if (a.ks == 3 && a.stride == 2) return 2;
-  if (a.force_tile >= 1 && a.force_tile <= 3 && a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.stride == 1 && !a.ups && !a.ups_fold &&
-      (a.force_tile != 1 || npad % 128 == 0)) return a.force_tile - 1;   // measurement aid (pf_conv_args.force_tile)
+  if (a.force_tile >= 1 && a.force_tile <= 3 && a.precision == PF_PREC_BF16X3 && a.stride == 1 && !a.ups && !a.ups_fold &&
+      (a.ks == 3 || a.a_planes) && (a.force_tile != 1 || npad % 128 == 0)) return a.force_tile - 1;   // measurement aid (pf_conv_args.force_tile)
   // bf16x3 3x3: the wide tile + split-K beats twice as many narrow tiles; planes GEMMs (both operands direct-to-LDS): one 128x128 workgroup
   // per CU beats two 128x64 ones as soon as every CU gets one (measured at M = 16384, N = 256: K = 256 18.1 -> 16.1 us, K = 1024 37.5 -> 33.9 us)
   // bf16x3 3x3 with 64 output channels in all (the 128x128 level): a 16x16-pixel tile when that still gives every CU two rounds of
