@@ -66,7 +66,7 @@ class ConvArgs(C.Structure):
         ("gn_stats0", C.c_void_p), ("gn_tiles0", C.c_int32), ("gn_stats1", C.c_void_p), ("gn_tiles1", C.c_int32),
         ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float), ("gn_groups", C.c_int32),
         ("sbias_rows", C.c_void_p), ("sbias_nrows", C.c_int32), ("no_t16", C.c_int32), ("no_pp", C.c_int32),
-        ("force_tile", C.c_int32), ("force_ksplit", C.c_int32),
+        ("force_tile", C.c_int32), ("force_ksplit", C.c_int32), ("x1_bmod", C.c_int32),
     ]
 
 
@@ -87,11 +87,15 @@ SIGNATURES = {
                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_unet_forward_prepared": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(UNetPrepared),
                                            C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pf_unet_forward_cfg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(UNetPrepared),
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_unet_time_bias_width": (C.c_int, [C.c_void_p]),
     "pf_unet_cross_bias_width": (C.c_int, [C.c_void_p]),
     "pf_unet_prepare_time": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_unet_prepare_cond": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_unet_n_launches_prepared": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pf_unet_workspace_bytes_cfg": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "pf_unet_n_launches_cfg": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pf_unet_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pf_unet_get_option": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_unet_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

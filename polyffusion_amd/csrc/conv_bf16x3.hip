@@ -143,6 +143,10 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   const int ty = mt - b * p.tiles_y;
   const int n0 = nti * BN;
   const int oy0 = ty * TH, ox0 = tx * TW;
+  conv_shared_x1(p, b);
+  // pixel the unconditional loads of padding / out-of-tile pieces read (their values are zeroed by the transform): pixel 0 of the first
+  // sample - or, with a rebased second source, of the sample the rebase points back to, so that the address stays inside both tensors
+  const int ppad = p.x1_bmod > 0 ? (b - b % p.x1_bmod) * p.Hin * p.Win : 0;
   // KS == 2: output row 2y+py reads source rows {y-1, y} (py = 0) or {y, y+1} (py = 1); same for columns
   const int iy0 = KS == 2 ? oy0 - 1 + (q >> 1) : oy0 * STRIDE - PAD, ix0 = KS == 2 ? ox0 - 1 + (q & 1) : ox0 * STRIDE - PAD;
   const int Hlog = UPS ? 2 * p.Hin : p.Hin, Wlog = UPS ? 2 * p.Win : p.Win;
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     for (int i = 0; i < NA; ++i) {
       // unconditional (padding / out-of-tile pieces read pixel 0 and are zeroed by the transform): the number of
       // vector loads in flight is then a compile-time constant, which the counted vmcnt waits of the 3x3 loop rely on
-      if (KS != 1 || poff[i] >= 0) ra[i] = *reinterpret_cast<const f32x4*>(src + co + (unsigned)(max(poff[i], 0) * cs + c4 * 4));
+      if (KS != 1 || poff[i] >= 0) ra[i] = *reinterpret_cast<const f32x4*>(src + co + (unsigned)(max(poff[i], ppad) * cs + c4 * 4));
       else ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (PRO == 1 || PRO == 2) {
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       // vmcnt(0) before the first use of an ordinary load's result, which drained the whole weight ring once per chunk.
       // The destination registers are read by transformSub only after the hand-placed vmcnt wait below.
       // (the buffer form that pays for the weight tiles was tried here too: no gain at 0.7 halo loads per tap - kept global)
-      if (i < NA) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[i]) : "v"(src + co + (unsigned)(max(poff[i], 0) * cs + c4 * 4)));
+      if (i < NA) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[i]) : "v"(src + co + (unsigned)(max(poff[i], ppad) * cs + c4 * 4)));
       else if (PRO == 1 || PRO == 2) {
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vsc) : "v"(p.sc + (size_t)b * cin + cg + c4 * 4));
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vsh) : "v"(p.sh + (size_t)b * cin + cg + c4 * 4));
@@ -959,6 +963,7 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
     p.gn_gamma = a.gn_gamma; p.gn_beta = a.gn_beta; p.gn_eps = a.gn_eps; p.gn_groups = a.gn_groups;
   }
   p.sx0 = a.skip_x0; p.sc0 = a.skip_c0; p.sx1 = a.skip_x1; p.sc1 = a.skip_c1; p.sw = a.skip_w; p.bias2 = a.skip_w ? a.skip_bias : nullptr;
+  p.x1_bmod = a.x1_bmod;
   const int tile = conv_pick_tile(a);
   if (a.ks == 1) {
     switch (a.prologue) {

@@ -77,7 +77,21 @@ struct ConvP {
   // GroupNorm finalize inside the consumer (bf16x3 kernels): per-tile statistics of the one or two producers, see gn_fused_prologue
   const float* gn_s0; const float* gn_s1; int gn_t0, gn_t1;
   const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_groups;
+  // x1_bmod > 0: the SECOND source (x1, sx1, gn_s1) holds only x1_bmod samples and sample b reads sample b % x1_bmod of it - the skip
+  // tensors of the classifier-free-guidance forward, whose conditional and unconditional halves share everything computed before the first
+  // transformer block (pf_unet_forward_cfg).  The kernels fold it into the base pointers once per workgroup (conv_shared_x1).
+  int x1_bmod;
 };
+
+// rebase the second-source pointers of this workgroup's sample (see ConvP::x1_bmod); hw_in / hw_out: pixels per sample of x1 / sx1
+__device__ __forceinline__ void conv_shared_x1(ConvP& p, int b) {
+  if (p.x1_bmod > 0) {
+    const size_t d = (size_t)(b - b % p.x1_bmod);
+    if (p.x1) p.x1 -= d * ((size_t)p.Hin * p.Win * p.c1);
+    if (p.sx1) p.sx1 -= d * ((size_t)p.Hout * p.Wout * p.sc1);
+    if (p.gn_s1) p.gn_s1 -= d * ((size_t)p.gn_t1 * p.c1 * 2);
+  }
+}
 
 static inline void conv_fill_divs(ConvP& p) {
   p.d_tx = make_fastdiv(p.tiles_x); p.d_ty = make_fastdiv(p.tiles_y); p.d_nt = make_fastdiv(p.nt); p.d_ks = make_fastdiv(p.ksplit);

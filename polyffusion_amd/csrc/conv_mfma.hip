@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
   const int tx = mt % p.tiles_x; mt /= p.tiles_x;
   const int ty = mt % p.tiles_y;
   const int b = mt / p.tiles_y;
+  conv_shared_x1(p, b);
   const int n0 = nti * BN;
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
@@ -370,7 +371,7 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
 
   ConvP p;
   memset(&p, 0, sizeof p);
-  p.x0 = a.x0; p.x1 = a.x1; p.c0 = a.c0; p.c1 = a.c1;
+  p.x0 = a.x0; p.x1 = a.x1; p.c0 = a.c0; p.c1 = a.c1; p.x1_bmod = a.x1_bmod;
   p.B = a.batch; p.Hin = a.hin; p.Win = a.win;
   p.Hout = a.hin; p.Wout = a.win;
   if (a.ups) { p.Hout *= 2; p.Wout *= 2; }

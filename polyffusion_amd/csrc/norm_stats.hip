@@ -63,8 +63,9 @@ __global__ __launch_bounds__(64) void gn_finalize_tiles_kernel(const float* __re
                                                                const float* __restrict__ s1, int t1, int c1, int hw, int groups,
                                                                float eps, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ scale,
-                                                               float* __restrict__ shift) {
+                                                               float* __restrict__ shift, int bmod1) {
   const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int b1 = bmod1 > 0 ? b % bmod1 : b;   // source 1 shared between the halves of a guidance batch (ConvP::x1_bmod)
   const int C = c0 + c1;
   const int gs = C / groups;
   double a = 0.0, q = 0.0;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(64) void gn_finalize_tiles_kernel(const float* __re
   const int n1 = gs - n0, cb1 = max(cb, c0) - c0;     // channels [cb1, cb1 + n1) of source 1
   for (int i = lane; i < n1 * t1; i += 64) {
     const int t = i / n1, cl = cb1 + i % n1;
-    const float2 v = *reinterpret_cast<const float2*>(s1 + (((size_t)b * t1 + t) * c1 + cl) * 2);
+    const float2 v = *reinterpret_cast<const float2*>(s1 + (((size_t)b1 * t1 + t) * c1 + cl) * 2);
     a += v.x; q += v.y;
   }
   for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); q += __shfl_xor(q, off); }
@@ -99,12 +100,12 @@ __global__ __launch_bounds__(64) void gn_finalize_tiles_kernel(const float* __re
 }
 
 int launch_gn_finalize_tiles(const float* s0, int t0, int c0, const float* s1, int t1, int c1, int batch, int hw, int groups,
-                             float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t stream) {
+                             float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t stream, int bmod1) {
   const int C = c0 + c1;
   PF_REQUIRE(s0 && t0 > 0 && c0 > 0 && (c1 == 0 || (s1 && t1 > 0)), "gn_finalize: bad statistics inputs");
   PF_REQUIRE(groups > 0 && C % groups == 0, "gn: groups=%d unsupported for C=%d", groups, C);
   hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(groups, batch), dim3(64), 0, stream, s0, t0, c0, s1, t1, c1, hw, groups, eps,
-                     gamma, beta, scale, shift);
+                     gamma, beta, scale, shift, bmod1);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }

@@ -77,7 +77,7 @@ int launch_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int 
                           const float* gamma, const float* beta, float* scale, float* shift, void* scratch,
                           size_t scratch_bytes, hipStream_t stream);
 int launch_gn_finalize_tiles(const float* s0, int t0, int c0, const float* s1, int t1, int c1, int batch, int hw, int groups,
-                             float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t stream);
+                             float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t stream, int bmod1 = 0);
 // per-split (sum, sumsq) of an NHWC tensor in the tile-statistics layout [B][gn_nsplit(hw)][C][2] (for tensors whose producer emits none)
 int gn_nsplit(int hw);
 int launch_gn_partial(const float* x0, int c0, const float* x1, int c1, int batch, int hw, float* stats, hipStream_t stream);

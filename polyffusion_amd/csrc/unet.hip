@@ -367,6 +367,7 @@ static int pack_one(const ParamSpec& ps, const float* src, float* blob) {
 struct Tn {
   const float* d = nullptr; int c = 0;
   const float* st = nullptr; int nt = 0;   // [B][nt][c][2] (sum, sumsq) or null
+  int bmod = 0;                            // > 0: the tensor (and its statistics) holds only bmod samples, shared by samples b and b + bmod (pf_unet_forward_cfg)
 };
 
 struct Ctx {
@@ -380,6 +381,9 @@ struct Ctx {
   bool has_time = false, has_cross = false;
   const float* prep_time = nullptr; int prep_time_rows = 0; const float* prep_cross = nullptr;
   const int64_t* t_rows = nullptr;   // with a time table: the per-sample row index = t
+  // classifier-free guidance with a shared prefix (pf_unet_forward_cfg): while `shared` the plan runs on the first Bfull / 2 samples only
+  bool cfg_share = false, shared = false; int Bfull = 0;
+  int x1mod(const Tn& x1) const { return (x1.c > 0 && x1.bmod > 0 && x1.bmod != B) ? x1.bmod : 0; }
 
   float* palloc(size_t nfloats) {
     size_t o = persist_off; persist_off += align_up(nfloats * 4, 256);
@@ -437,13 +441,13 @@ struct Ctx {
   // `fuse_ok`: the consumer is a bf16x3 conv that can do this reduction in its own prologue (pf_conv_args.gn_*): worth it when a
   // sample has few statistics tiles (the 32x32 / 16x16 levels: <= 16 tiles), where the 5 us finalize launch is 10-20 % of the
   // convolution it feeds; at the 128x128 / 64x64 levels every consumer workgroup would re-read 32-64 KB, so the launch stays.
-  struct GnRef { bool fused = false; const float* s0 = nullptr; const float* s1 = nullptr; int t0 = 0, t1 = 0; size_t g = 0, b = 0; float eps = 0.f; };
+  struct GnRef { bool fused = false; const float* s0 = nullptr; const float* s1 = nullptr; int t0 = 0, t1 = 0; size_t g = 0, b = 0; float eps = 0.f; int bmod1 = 0; };
   GnRef gn(const Tn& x0, const Tn& x1, int hw, float eps, size_t g, size_t b_, float* sc, float* sh, bool fuse_ok = false) {
     const int cin_ = x0.c + x1.c;
     // (<= 32 tiles - the 64x64 level too - measured neutral in round 5 with the batched statistics loads, -0.9 % before them; <= 128: -3 %)
     constexpr int fold_max = 16;
     if (fuse_ok && u->precision == PF_PREC_BF16X3 && cin_ % 32 == 0 && cin_ <= 1024 && x0.nt <= fold_max && (x1.c == 0 || x1.nt <= fold_max)) {
-      GnRef r; r.fused = true; r.s0 = x0.st; r.t0 = x0.nt; r.s1 = x1.st; r.t1 = x1.nt; r.g = g; r.b = b_; r.eps = eps;
+      GnRef r; r.fused = true; r.s0 = x0.st; r.t0 = x0.nt; r.s1 = x1.st; r.t1 = x1.nt; r.g = g; r.b = b_; r.eps = eps; r.bmod1 = x1mod(x1);
       return r;
     }
     gn_launch(x0, x1, hw, eps, g, b_, sc, sh);
@@ -457,7 +461,7 @@ struct Ctx {
   void gn_launch(const Tn& x0, const Tn& x1, int hw, float eps, size_t g, size_t b_, float* sc, float* sh) {
     prof_begin(PF_K_GNSTAT, 0.0);
     if (!dry && rc == PF_OK)
-      rc = launch_gn_finalize_tiles(x0.st, x0.nt, x0.c, x1.st, x1.nt, x1.c, B, hw, 32, eps, w(g), w(b_), sc, sh, s);
+      rc = launch_gn_finalize_tiles(x0.st, x0.nt, x0.c, x1.st, x1.nt, x1.c, B, hw, 32, eps, w(g), w(b_), sc, sh, s, x1mod(x1));
     prof_end();
   }
   // statistics for a tensor whose producer emitted none (the stem conv output)
@@ -505,6 +509,7 @@ static Tn run_res(Ctx& c, const Layer& L, const Tn& x0, const Tn& x1, int H, int
     c.gn_attach(a, g1);
     a.sbias = c.dry ? nullptr : tb_all + L.emb_off; a.ld_sbias = c.u->sum_emb;
     a.sbias_rows = c.t_rows; a.sbias_nrows = c.prep_time_rows;   // hoisted table: row = t[b]
+    a.x1_bmod = c.x1mod(x1);
     c.conv(a, PF_K_CONV3, &ht, false);
   }
   const Ctx::GnRef g2 = c.gn(ht, Tn{}, hw, 1e-5f, L.gn2_g, L.gn2_b, sc2, sh2, true);
@@ -516,6 +521,7 @@ static Tn run_res(Ctx& c, const Layer& L, const Tn& x0, const Tn& x1, int H, int
     float* sk = c.talloc((size_t)B * hw * co);
     pf_conv_args a = conv_base(x0.d, x0.c, x1.d, x1.c, B, 1, hw, 1, c.w(L.wskip), co, sk);
     a.bias = c.w(L.bskip);
+    a.x1_bmod = c.x1mod(x1);
     c.conv(a, PF_K_GEMM);
     res = sk;
   }
@@ -528,6 +534,7 @@ static Tn run_res(Ctx& c, const Layer& L, const Tn& x0, const Tn& x1, int H, int
       a.skip_x0 = x0.d; a.skip_c0 = x0.c; a.skip_x1 = x1.d; a.skip_c1 = x1.c;
       a.skip_w = c.dry ? (const void*)1 : (const void*)(c.w(L.wskip) + (size_t)ci * ((co + 63) / 64 * 64));   // its bf16x3 packing
       a.skip_bias = c.w(L.bskip);
+      a.x1_bmod = c.x1mod(x1);
     } else {
       a.res = res; a.ld_res = co;
     }
@@ -760,10 +767,35 @@ static int run(pf_unet* u, Ctx& c, const float* x, const int64_t* t, const float
 
   std::vector<Tn> skips;
   Tn cur;
+  // Classifier-free guidance with a shared prefix: until the first SpatialTransformer the plan runs on the first half of the batch only
+  // (the two halves are identical there: the condition has not entered yet); right before it the running tensor and its statistics are
+  // duplicated and the plan continues on the whole batch.  Skip tensors produced in the shared phase keep their half size and are read
+  // with the sample index modulo the half (Tn::bmod -> pf_conv_args.x1_bmod).
+  if (c.cfg_share) { c.Bfull = c.B; c.B = c.B / 2; c.shared = true; }
+  auto dup_rows = [&](const float* src, size_t floats_per_half) -> const float* {
+    float* dst = c.palloc(2 * floats_per_half);
+    for (int h = 0; h < 2; ++h) {
+      c.prof_begin(PF_K_SMALL, 0);
+      if (!c.dry && c.rc == PF_OK && hipMemcpyAsync(dst + h * floats_per_half, src, floats_per_half * sizeof(float), hipMemcpyDeviceToDevice, c.s) != hipSuccess)
+        c.rc = set_error(PF_EHIP, "pf_unet_forward_cfg: device copy failed");
+      c.prof_end();
+    }
+    return dst;
+  };
+  auto leave_shared_phase = [&](Tn& a0, int h, int w_) {
+    if (!c.shared) return;
+    const int Bh = c.B;
+    a0.d = dup_rows(a0.d, (size_t)Bh * h * w_ * a0.c);
+    if (a0.nt > 0) a0.st = dup_rows(a0.st, (size_t)Bh * a0.nt * a0.c * 2);   // (nt, not st: a dry run carries no pointers)
+    a0.bmod = 0;
+    c.B = c.Bfull; c.shared = false;
+  };
   auto run_layers = [&](const Block& b, Tn in0, Tn in1) {
     Tn a0 = in0, a1 = in1;
     for (const Layer& L : b.layers) {
       Tn o;
+      if (L.kind == 2) leave_shared_phase(a0, H, W_);
+      const int B = c.B;
       switch (L.kind) {
         case 0: {
           float* od = c.palloc((size_t)B * H * W_ * L.cout);
@@ -803,6 +835,7 @@ static int run(pf_unet* u, Ctx& c, const float* x, const int64_t* t, const float
         }
       }
       if (c.dry) o.c = L.cout;
+      if (c.shared) o.bmod = c.B;
       a0 = o; a1 = Tn{};
     }
     cur = a0;
@@ -820,17 +853,27 @@ static int run(pf_unet* u, Ctx& c, const float* x, const int64_t* t, const float
   }
   // out: GN + SiLU + conv3x3 -> NCHW
   c.treset();
-  float* sc = c.talloc((size_t)B * cur.c); float* sh = c.talloc((size_t)B * cur.c);
+  const int Bo = c.B;   // (still the half batch only for a UNet without any transformer block: eps is then duplicated below)
+  float* sc = c.talloc((size_t)Bo * cur.c); float* sh = c.talloc((size_t)Bo * cur.c);
   c.gn(cur, Tn{}, H * W_, 1e-5f, u->out_g, u->out_b, sc, sh);
-  c.prof_begin(PF_K_SMALL, 2.0 * B * H * W_ * 9.0 * cur.c * cfg.out_channels);
-  if (!c.dry) small_launch(c, launch_conv_out(cur.d, sc, sh, c.w(u->out_w), c.w(u->out_bias), eps, B, cur.c, cfg.out_channels, H, W_, c.s));
+  c.prof_begin(PF_K_SMALL, 2.0 * Bo * H * W_ * 9.0 * cur.c * cfg.out_channels);
+  if (!c.dry) small_launch(c, launch_conv_out(cur.d, sc, sh, c.w(u->out_w), c.w(u->out_bias), eps, Bo, cur.c, cfg.out_channels, H, W_, c.s));
   c.prof_end();
+  if (c.shared) {   // no layer ever looked at the condition: both halves of eps are the same image
+    const size_t n = (size_t)Bo * cfg.out_channels * H * W_;
+    c.prof_begin(PF_K_SMALL, 0);
+    if (!c.dry && c.rc == PF_OK && hipMemcpyAsync(eps + n, eps, n * sizeof(float), hipMemcpyDeviceToDevice, c.s) != hipSuccess)
+      c.rc = set_error(PF_EHIP, "pf_unet_forward_cfg: device copy failed");
+    c.prof_end();
+    c.B = c.Bfull; c.shared = false;
+  }
   return c.rc;
 }
 
-static void plan_sizes(pf_unet* u, int batch, int n_cond, size_t* persist, size_t* temp, int* launches, bool has_time = false, bool has_cross = false) {
+static void plan_sizes(pf_unet* u, int batch, int n_cond, size_t* persist, size_t* temp, int* launches, bool has_time = false, bool has_cross = false,
+                       bool cfg_share = false) {
   Ctx c{};
-  c.u = u; c.dry = true; c.B = batch; c.n_cond = n_cond; c.rc = PF_OK; c.has_time = has_time; c.has_cross = has_cross;
+  c.u = u; c.dry = true; c.B = batch; c.n_cond = n_cond; c.rc = PF_OK; c.has_time = has_time; c.has_cross = has_cross; c.cfg_share = cfg_share;
   run(u, c, nullptr, nullptr, nullptr, nullptr);
   *persist = align_up(c.persist_max, 4096);
   *temp = align_up(c.temp_max, 4096);
@@ -927,25 +970,50 @@ int pf_unet_forward(pf_unet* u, const float* x, const int64_t* t, const float* c
   return pf_unet_forward_prepared(u, x, t, cond, batch, n_cond, nullptr, eps, workspace, workspace_bytes, stream);
 }
 
-int pf_unet_forward_prepared(pf_unet* u, const float* x, const int64_t* t, const float* cond, int batch, int n_cond, const pf_unet_prepared* prep,
-                             float* eps, void* workspace, size_t workspace_bytes, void* stream) {
+static int forward_impl(pf_unet* u, const float* x, const int64_t* t, const float* cond, int batch, int n_cond, const pf_unet_prepared* prep,
+                        float* eps, void* workspace, size_t workspace_bytes, void* stream, bool cfg_share) {
   PF_REQUIRE(u && x && t && cond && eps && workspace, "pf_unet_forward: null argument");
   PF_REQUIRE(!prep || !prep->time_table || prep->n_time_rows > 0, "pf_unet_forward: time table without rows");
   PF_REQUIRE(!prep || !prep->cross_bias || n_cond == 1, "pf_unet_forward: the collapsed cross-attention bias exists only for n_cond == 1");
   PF_REQUIRE(batch > 0 && n_cond > 0, "pf_unet_forward: batch and n_cond must be positive");
+  PF_REQUIRE(!cfg_share || batch % 2 == 0, "pf_unet_forward_cfg: the batch is the two guidance halves (got %d)", batch);
   if (!u->wdev) return set_error(PF_ESTATE, "pf_unet_forward: weights not bound (call pf_unet_bind_weights)");
   PF_REQUIRE(n_cond == 1 || u->cfg.d_cond % 32 == 0, "pf_unet_forward: n_cond > 1 needs d_cond %% 32 == 0");
   PF_REQUIRE(((uintptr_t)workspace & 255) == 0, "pf_unet_forward: workspace must be 256-byte aligned");
   size_t p, tmp;
-  plan_sizes(u, batch, n_cond, &p, &tmp, nullptr);
+  plan_sizes(u, batch, n_cond, &p, &tmp, nullptr, false, false, cfg_share);
   if (workspace_bytes < p + tmp) return set_error(PF_EINVAL, "pf_unet_forward: workspace too small (%zu < %zu)", workspace_bytes, p + tmp);
   Ctx c{};
   c.u = u; c.s = (hipStream_t)stream; c.dry = false; c.base = (char*)workspace; c.temp_base = p;
-  c.B = batch; c.n_cond = n_cond; c.W = u->wdev; c.rc = PF_OK;
+  c.B = batch; c.n_cond = n_cond; c.W = u->wdev; c.rc = PF_OK; c.cfg_share = cfg_share;
   if (prep && prep->time_table) { c.has_time = true; c.prep_time = prep->time_table; c.prep_time_rows = prep->n_time_rows; }
   if (prep && prep->cross_bias && u->cross_total > 0) { c.has_cross = true; c.prep_cross = prep->cross_bias; }
   if (u->profiling) { u->n_prof = 0; u->pkind.clear(); u->pflops.clear(); }
   return run(u, c, x, t, cond, eps);
+}
+
+int pf_unet_forward_prepared(pf_unet* u, const float* x, const int64_t* t, const float* cond, int batch, int n_cond, const pf_unet_prepared* prep,
+                             float* eps, void* workspace, size_t workspace_bytes, void* stream) {
+  return forward_impl(u, x, t, cond, batch, n_cond, prep, eps, workspace, workspace_bytes, stream, false);
+}
+
+int pf_unet_forward_cfg(pf_unet* u, const float* x, const int64_t* t, const float* cond, int batch2, int n_cond, const pf_unet_prepared* prep,
+                        float* eps2, void* workspace, size_t workspace_bytes, void* stream) {
+  return forward_impl(u, x, t, cond, batch2, n_cond, prep, eps2, workspace, workspace_bytes, stream, true);
+}
+
+size_t pf_unet_workspace_bytes_cfg(const pf_unet* u, int batch2, int n_cond) {
+  if (!u || batch2 <= 0 || batch2 % 2 || n_cond <= 0) return 0;
+  size_t p, t;
+  plan_sizes(const_cast<pf_unet*>(u), batch2, n_cond, &p, &t, nullptr, false, false, true);
+  return p + t;
+}
+
+int pf_unet_n_launches_cfg(const pf_unet* u, int batch2, int n_cond, int has_time, int has_cross) {
+  if (!u || batch2 <= 0 || batch2 % 2 || n_cond <= 0) return 0;
+  size_t p, t; int n = 0;
+  plan_sizes(const_cast<pf_unet*>(u), batch2, n_cond, &p, &t, &n, has_time != 0, has_cross != 0 && n_cond == 1, true);
+  return n;
 }
 
 int pf_unet_time_bias_width(const pf_unet* u) { return u ? u->sum_emb : 0; }

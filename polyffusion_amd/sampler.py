@@ -48,6 +48,9 @@ class DiffusionSampler:
         self.seed = int(seed)
         self.sample_offset = int(sample_offset)  # global index of this rank's first sample (multi-GPU sharding)
         self._draws = 0
+        # classifier-free guidance evaluates the denoiser on cat([x, x]); the part of it that cannot depend on the condition is shared
+        # between the halves unless this is switched off (results equal up to tile-choice rounding; tests compare both)
+        self.share_cfg_prefix = True
         self._lib = _lib.load()
         self._trows = None
         # graph=True: paint() captures ONE reverse step as a hipGraph and replays it.  What varies per step
@@ -184,7 +187,12 @@ class DiffusionSampler:
             return self.model(x, t, uncond_cond, **kw)
         # re-concatenated on every call like the reference (sampler/__init__.py:69-74): [2B,n_cond,d_cond] is a few KB, and a
         # cache keyed on addresses could serve a stale tensor after an in-place update or an allocator address reuse
-        eps2 = self.model(torch.cat([x, x]), torch.cat([t, t]), torch.cat([uncond_cond, c]), **kw)
+        if self.share_cfg_prefix and getattr(self.model, "supports_shared_x", False):
+            # the two halves see the same x and t and differ only in the condition, which enters the UNet at its first transformer
+            # block: everything in front of it is evaluated once for both (UNetModel.forward(shared_x=True), pf_unet_forward_cfg)
+            eps2 = self.model(x, torch.cat([t, t]), torch.cat([uncond_cond, c]), shared_x=True, **kw)
+        else:
+            eps2 = self.model(torch.cat([x, x]), torch.cat([t, t]), torch.cat([uncond_cond, c]), **kw)
         e_t = torch.empty_like(eps2[: x.shape[0]])   # eps has out_channels; x may carry extra cond_concat channels
         _lib.check(self._lib.pf_cfg_combine(eps2.data_ptr(), float(uncond_scale), e_t.data_ptr(), e_t.numel(),
                                             _lib.current_stream()), "pf_cfg_combine")

@@ -109,11 +109,12 @@ class UNetModel:
         return self
 
     # ---- forward --------------------------------------------------------------------------------
-    def workspace(self, batch: int, n_cond: int) -> torch.Tensor:
-        # tile choice (and buffer sizes) depend on the arithmetic mode and on the plan options
-        key = (batch, n_cond, self._lib.pf_unet_get_precision(self._h)) + self.options_key()
+    def workspace(self, batch: int, n_cond: int, shared_x: bool = False) -> torch.Tensor:
+        # tile choice (and buffer sizes) depend on the arithmetic mode and on the plan options; the shared-prefix guidance plan has a layout of its own
+        key = (batch, n_cond, shared_x, self._lib.pf_unet_get_precision(self._h)) + self.options_key()
         if self._ws is None or self._ws_key != key:
-            nbytes = self._lib.pf_unet_workspace_bytes(self._h, batch, n_cond)
+            size = self._lib.pf_unet_workspace_bytes_cfg if shared_x else self._lib.pf_unet_workspace_bytes
+            nbytes = size(self._h, batch, n_cond)
             if self._ws is None or self._ws.numel() < nbytes:
                 self._ws = None
                 self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -156,23 +157,30 @@ class UNetModel:
         return out
 
     def forward(self, x: torch.Tensor, time_steps: torch.Tensor, cond: torch.Tensor, out: Optional[torch.Tensor] = None, *,
-                time_table: Optional[torch.Tensor] = None, cross_bias: Optional[torch.Tensor] = None, check_t: bool = False):
+                time_table: Optional[torch.Tensor] = None, cross_bias: Optional[torch.Tensor] = None, check_t: bool = False,
+                shared_x: bool = False):
         """``time_table`` / ``cross_bias``: results of ``prepare_time`` / ``prepare_cond(cond)`` - the caller vouches that they
         belong to these weights and this ``cond``; either may be ``None`` (computed here).  Bit-identical either way.
+        ``shared_x=True`` - classifier-free guidance (``sampler/__init__.py:69-74``): ``x`` holds B samples while ``time_steps`` and
+        ``cond`` hold the 2B rows of ``cat([t, t])`` / ``cat([uncond_cond, cond])``; the result equals ``forward(cat([x, x]), ...)`` up to
+        tile-choice rounding, but everything in front of the first transformer block - where the two halves cannot differ - is computed
+        once (``pf_unet_forward_cfg``).
         The prepared path is valid for ``0 <= t < time_table.shape[0]`` only; ``check_t=True`` verifies that (one device->host
         sync - the samplers, whose t values are rows of a host-built table, do not ask for it)."""
         if self._blob_dev is None:
             raise RuntimeError("UNetModel.forward: weights not loaded")
-        B = x.shape[0]
+        B = x.shape[0] * (2 if shared_x else 1)
         if tuple(x.shape[1:]) != (self.cfg.in_channels, self.img_h, self.img_w):
             raise RuntimeError(f"UNetModel.forward: x has shape {tuple(x.shape)}, expected [B,{self.cfg.in_channels},{self.img_h},{self.img_w}]")
         if cond.dim() != 3 or cond.shape[0] != B or cond.shape[2] != self.cfg.d_cond:
-            raise RuntimeError(f"UNetModel.forward: cond has shape {tuple(cond.shape)}, expected [B,n_cond,{self.cfg.d_cond}]")
+            raise RuntimeError(f"UNetModel.forward: cond has shape {tuple(cond.shape)}, expected [{'2B' if shared_x else 'B'},n_cond,{self.cfg.d_cond}]")
+        if time_steps.shape[0] != B:
+            raise RuntimeError(f"UNetModel.forward: {time_steps.shape[0]} time steps for {B} condition rows")
         x = x.contiguous().float()
         cond = cond.contiguous().float()
         t = time_steps.to(torch.int64).contiguous()
         n_cond = cond.shape[1]
-        ws = self.workspace(B, n_cond)
+        ws = self.workspace(B, n_cond, shared_x)
         if out is None:
             out = torch.empty(B, self.cfg.out_channels, self.img_h, self.img_w, dtype=torch.float32, device=x.device)
         prep = None
@@ -192,9 +200,9 @@ class UNetModel:
             if cross_bias is not None:
                 assert n_cond == 1 and cross_bias.shape[0] == B and cross_bias.is_contiguous() and cross_bias.device == x.device
                 prep.cross_bias = cross_bias.data_ptr()
-        _lib.check(self._lib.pf_unet_forward_prepared(self._h, x.data_ptr(), t.data_ptr(), cond.data_ptr(), B, n_cond,
-                                                      None if prep is None else C.byref(prep), out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                      _lib.current_stream()), "pf_unet_forward")
+        fn = self._lib.pf_unet_forward_cfg if shared_x else self._lib.pf_unet_forward_prepared
+        _lib.check(fn(self._h, x.data_ptr(), t.data_ptr(), cond.data_ptr(), B, n_cond, None if prep is None else C.byref(prep), out.data_ptr(),
+                      ws.data_ptr(), ws.numel(), _lib.current_stream()), "pf_unet_forward")
         return out
 
     __call__ = forward
@@ -239,7 +247,9 @@ class UNetModel:
         n = _lib.check(self._lib.pf_unet_profile_read(self._h, kind, ms, fl, cap))
         return [(kind[i], ms[i], fl[i]) for i in range(n)]
 
-    def n_launches(self, batch: int, n_cond: int = 1, prepared: bool = False) -> int:
+    def n_launches(self, batch: int, n_cond: int = 1, prepared: bool = False, shared_x: bool = False) -> int:
+        if shared_x:     # batch = the 2B rows of a guidance evaluation
+            return int(self._lib.pf_unet_n_launches_cfg(self._h, batch, n_cond, int(prepared), int(prepared)))
         if prepared:
             return int(self._lib.pf_unet_n_launches_prepared(self._h, batch, n_cond, 1, 1))
         return int(self._lib.pf_unet_n_launches(self._h, batch, n_cond))
@@ -272,6 +282,8 @@ class LatentDiffusion:
 
     def eval(self):
         return self
+
+    supports_shared_x = True     # forward(..., shared_x=True): the guidance evaluation with its condition-independent prefix computed once
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, context: torch.Tensor, **prepared):
         return self.eps_model(x, t, context, **prepared)
