@@ -369,10 +369,28 @@ def config3_line(model, params, steps=10, windows=3, probe=None):
     med, all_s, mhz = windowed(lambda: run(steps), windows, probe)
     assert torch.isfinite(out[0]).all()
     f_eval = F_MIN_PER_SAMPLE_EVAL - F_UPFOLD_SAVED
+    # work actually executed: the guidance evaluation computes everything in front of the first transformer block once for both halves
+    # (pf_unet_forward_cfg).  The prefix's FLOPs are read off a profiled plain evaluation: every launch before the first linear layer.
+    unet = model.ldm.eps_model
+    shared = 0.0
+    if d.share_cfg_prefix:
+        unet.set_profiling(True)
+        unet(x[:2], torch.full((2,), 999, dtype=torch.long, device=dev), cond[:2])
+        torch.cuda.synchronize()
+        for kind, _ms, fl in unet.read_profile():
+            if kind == 1:
+                break
+            shared += fl / 2.0
+        unet.set_profiling(False)
+    executed = f_eval * 64 - shared * 32
     return {"workload": "sdf_chd8bar DDIM 50-step, uncond_scale 5, batch 32 (64 UNet sample-evals per step), 1 GPU", "steps": steps, "windows": windows,
             "steps_per_s": round(steps / med, 3), "ms_per_step": round(med / steps * 1e3, 3), "sample_evals_per_s": round(64 * steps / med, 1),
             "windows_ms_per_step": [round(t / steps * 1e3, 3) for t in all_s], "sclk_mhz": mhz,
-            "roofline_frac": round(f_eval * 64 * steps / med / (PEAK_ALGO["bf16x3"] * 1e12), 4)}
+            "shared_prefix": {"on": bool(d.share_cfg_prefix), "gflop_per_sample": round(shared / 1e9, 3),
+                              "note": "layers in front of the first transformer block are evaluated on 32 samples instead of 64 (identical for the "
+                                      "conditional and unconditional halves); roofline_frac counts the executed work only"},
+            "executed_gflop_per_step": round(executed / 1e9, 1),
+            "roofline_frac": round(executed * steps / med / (PEAK_ALGO["bf16x3"] * 1e12), 4)}
 
 
 def config4_line(steps=20, windows=3, probe=None):
