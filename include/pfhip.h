@@ -365,6 +365,13 @@ int pf_conv2d(const pf_conv_args* a, void* stream);
  * the result goes to fp32 `o` or, when o_planes != NULL, to bf16 hi/lo planes [M][C] | [M][C] for a following planes GEMM */
 int pf_attention_bf16x3(const void* qkv_planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, int form /* PF_OPT_AUTO | 0: 128-query | 1: 256-query workgroups */,
                         void* stream);
+/* The same attention for SMALL batches (128-query form): when (l / 128) * n_heads * batch workgroups would leave three quarters of the CUs idle and
+ * l %% 512 == 0 (batch 1 / 2 at L = 1024), the keys of every query tile are split over four workgroups - each leaves its un-normalised partial result,
+ * running maximum and row sum in `scratch` - and a second launch merges them (the online-softmax combination; equal to the one-launch form up to
+ * summation order).  scratch_bytes >= pf_attention_split_scratch_bytes(batch, n_heads, l) (0 = this shape does not split: one launch, scratch unused). */
+size_t pf_attention_split_scratch_bytes(int batch, int n_heads, int l);
+int pf_attention_bf16x3_split(const void* qkv_planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, void* scratch, size_t scratch_bytes,
+                              void* stream);
 int pf_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                  int batch, int n_heads, int d_head, int lq, int lk, void* stream);
 

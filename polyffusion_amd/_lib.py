@@ -152,6 +152,8 @@ SIGNATURES = {
     "pf_gn_finalize_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_attention_bf16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pf_attention_split_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "pf_attention_bf16x3_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }

@@ -33,6 +33,9 @@ struct AttnP3 {
   int B, H, L;
   float scale;
   FastDiv d_nqt, d_h;     // reciprocals of the query tiles per (batch, head) and of H (tile decode without emulated divisions)
+  // key split (small batches: 128-query form only): nsplit > 1 workgroups share a query tile, each walks L / nsplit keys and leaves its
+  // un-normalised O^T with the running maximum and row sum in part_o / part_ml; attn_merge_kernel combines them
+  int nsplit; float* part_o; float* part_ml; FastDiv d_ns;
 };
 
 // NWAVES waves x 32 queries per workgroup share every K / V^T tile; RING tile stages in LDS (32 KB each).
@@ -58,6 +61,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
     const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
   }
+  int sp = 0;
+  if (p.nsplit > 1) { const int t = fdiv(lid, p.d_ns); sp = lid - t * p.nsplit; lid = t; }   // key slice (fastest: the slices of a query tile run together)
   const int bh = fdiv(lid, p.d_nqt), qt = lid - bh * nqt;
   const int b = fdiv(bh, p.d_h), h = bh - b * p.H;
 #ifdef PF_TRACE
@@ -107,7 +112,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
     for (int r = 0; r < 16; ++r) oacc[df][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntile = L / KT;            // even: L is a multiple of 128
+  const int ntile_all = L / KT;        // even: L is a multiple of 128
+  const int ntile = ntile_all / p.nsplit, tile0 = sp * ntile;   // this workgroup's keys: tiles [tile0, tile0 + ntile), ntile a multiple of RING (launcher)
   const int r31 = lane & 31;
   // LDS byte address of this lane's fragment row inside an 8 KB array, one per K-step pair: row = r31 (+32 per fragment,
   // an immediate), 16-byte slot = (2 sp + g) ^ ((row >> 1) & 7).  K and V^T fragments share the formula (row = key or channel).
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     TRA();
-    const int tn = min(t + RING - 1, ntile - 1);
+    const int tn = tile0 + min(t + RING - 1, ntile - 1);
     constexpr int STN = (ST + RING - 1) % RING;
 
     // ---- S^T = K . Q^T ----
@@ -234,12 +240,24 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
   };
   TRA();
 #pragma unroll
-  for (int d = 0; d < RING - 1; ++d) issue_tile(min(d, ntile - 1), d);
+  for (int d = 0; d < RING - 1; ++d) issue_tile(tile0 + min(d, ntile - 1), d);
   for (int t = 0; t < ntile; t += RING)   // ntile is a multiple of RING (launcher)
     static_for<0, RING>([&](auto st) { tile_body(st, t + decltype(st)::value); });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail prefetch
 #undef SB
 
+  if (p.nsplit > 1) {   // partial result of this key slice: O^T as accumulated (relative to m_run), m_run, the row sum
+    const size_t row = (((size_t)sp * p.B + b) * p.H + h) * L + qi;
+    float* po = p.part_o + row * DH;
+#pragma unroll
+    for (int df = 0; df < 2; ++df)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<f32x4*>(po + df * 32 + 8 * c + 4 * g) = f32x4{oacc[df][4 * c + 0], oacc[df][4 * c + 1], oacc[df][4 * c + 2], oacc[df][4 * c + 3]};
+    const float lsum = l_run + __shfl_xor(l_run, 32);
+    if (g == 0) { p.part_ml[row * 2] = m_run; p.part_ml[row * 2 + 1] = lsum; }
+    return;
+  }
   const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
   float* op = p.o + ((size_t)b * L + qi) * p.ldo + h * DH;
 #pragma unroll
@@ -586,14 +604,58 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
   }
 }
 
-int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, int form, hipStream_t stream) {
+// Combine the key slices of the split form: out[q] = sum_s 2^(m_s - m) O_s[q] / sum_s 2^(m_s - m) l_s with m = max_s m_s (the online-softmax
+// merge, in the exp2 domain the kernel works in).  One thread per (query, four channels); fp32 rows or hi/lo planes like the kernel's own store.
+__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, int nsplit, int B, int H, int L,
+                                                        float* __restrict__ o, int ldo, __bf16* __restrict__ o_planes) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;     // over B*H*L*16
+  const size_t nrow = (size_t)B * H * L;
+  if (i >= nrow * 16) return;
+  const size_t row = i >> 4; const int c4 = (int)(i & 15) * 4;
+  float m = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) m = fmaxf(m, part_ml[(s * nrow + row) * 2]);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}; float lsum = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float w = exp2f(part_ml[(s * nrow + row) * 2] - m);
+    lsum += w * part_ml[(s * nrow + row) * 2 + 1];
+    acc += *reinterpret_cast<const f32x4*>(part_o + (s * nrow + row) * 64 + c4) * w;
+  }
+  const f32x4 v = acc * (1.0f / lsum);
+  const int q = (int)(row % L); const size_t bh = row / L; const int h = (int)(bh % H); const size_t b = bh / H;
+  const int C = H * 64;
+  if (o_planes) {
+    const size_t MC = (size_t)B * L * C;
+    const bf16x4 h4 = __builtin_convertvector(v, bf16x4);
+    const bf16x4 l4 = __builtin_convertvector(v - __builtin_convertvector(h4, f32x4), bf16x4);
+    __bf16* pp = o_planes + (b * L + q) * C + h * 64 + c4;
+    *reinterpret_cast<bf16x4*>(pp) = h4;
+    *reinterpret_cast<bf16x4*>(pp + MC) = l4;
+  } else {
+    *reinterpret_cast<f32x4*>(o + (b * L + q) * ldo + h * 64 + c4) = v;
+  }
+}
+
+// scratch floats the key-split form wants for (batch, n_heads, l): 0 = it would not split
+size_t attention_bf3_split_floats(int batch, int n_heads, int l, int* nsplit_out) {
+  int ns = 1;
+  // few workgroups walking many key tiles (batch 1 / 2 at L = 1024: 32 / 64 workgroups x 16 tiles): four key slices per query tile
+  if (l % 512 == 0 && (l / 128) * n_heads * batch * 4 <= num_cus()) ns = 4;
+  if (nsplit_out) *nsplit_out = ns;
+  return ns > 1 ? (size_t)ns * batch * n_heads * l * (64 + 2) : 0;
+}
+
+int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, int form, hipStream_t stream,
+                         float* scratch, size_t scratch_floats) {
   PF_REQUIRE(planes && (o || o_planes) && batch > 0 && n_heads > 0 && l > 0 && l % 128 == 0, "attention_bf3: L must be a positive multiple of 128");
   PF_REQUIRE(form == PF_OPT_AUTO || form == 0 || (form == 1 && l % 256 == 0), "attention_bf3: form must be auto, 0 (128-query) or 1 (256-query, L %% 256 == 0)");
   PF_REQUIRE((size_t)batch * l * n_heads * 64 * 2 * 2 < ((size_t)1 << 31), "attention_bf3: a plane pair must stay below 2 GiB (32-bit offsets of the direct-to-LDS loads)");
   // auto: the 256-query form where it still gives three quarters of the CUs a workgroup
   const bool wide = l % 256 == 0 && (form == PF_OPT_AUTO ? (l / 256) * n_heads * batch >= num_cus() * 3 / 4 : form == 1);
   AttnP3 p{static_cast<const __bf16*>(planes), o, ldo, static_cast<__bf16*>(o_planes), batch, n_heads, l, 0.125f,
-           make_fastdiv(wide ? l / 256 : l / 128), make_fastdiv(n_heads)};
+           make_fastdiv(wide ? l / 256 : l / 128), make_fastdiv(n_heads), 1, nullptr, nullptr, make_fastdiv(1)};
+  int ns = 1;
+  const size_t want = wide ? 0 : attention_bf3_split_floats(batch, n_heads, l, &ns);
+  const bool split = !wide && ns > 1 && scratch && scratch_floats >= want;
   // (an 8-wave / 256-query form - half the K/V^T tile traffic per query - was measured and lost: its waves run S / softmax / PV in
   // lockstep behind one barrier, so the matrix pipe idles during every softmax, while two independent 4-wave workgroups per CU drift
   // apart and fill each other's gaps)
@@ -601,7 +663,15 @@ int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, 
   if (int rc = set_max_lds_once(reinterpret_cast<const void*>(attn_bf3_kernel<4, 2>), 2 * 32768, done_n)) return rc;
   if (int rc = set_max_lds_once(reinterpret_cast<const void*>(attn_bf3_wide_kernel<4>), 4 * 32768, done_w)) return rc;
   if (wide) hipLaunchKernelGGL((attn_bf3_wide_kernel<4>), dim3((l / 256) * n_heads * batch), dim3(256), 4 * 32768, stream, p);
-  else hipLaunchKernelGGL((attn_bf3_kernel<4, 2>), dim3((l / 128) * n_heads * batch), dim3(256), 2 * 32768, stream, p);
+  else if (split) {
+    p.nsplit = ns; p.d_ns = make_fastdiv(ns);
+    p.part_o = scratch; p.part_ml = scratch + (size_t)ns * batch * n_heads * l * 64;
+    hipLaunchKernelGGL((attn_bf3_kernel<4, 2>), dim3((l / 128) * n_heads * batch * ns), dim3(256), 2 * 32768, stream, p);
+    PF_CHECK_HIP(hipGetLastError());
+    const size_t n16 = (size_t)batch * n_heads * l * 16;
+    hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, stream, p.part_o, p.part_ml, ns, batch, n_heads, l, o, ldo,
+                       static_cast<__bf16*>(o_planes));
+  } else hipLaunchKernelGGL((attn_bf3_kernel<4, 2>), dim3((l / 128) * n_heads * batch), dim3(256), 2 * 32768, stream, p);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }

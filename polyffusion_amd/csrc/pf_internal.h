@@ -59,7 +59,10 @@ int launch_attention(const float* q, int ldq, const float* k, int ldk, const flo
                      int batch, int n_heads, int d_head, int lq, int lk, hipStream_t stream);
 
 // form: PF_OPT_AUTO | 0 = 128-query workgroups | 1 = 256-query workgroups (needs l % 256 == 0)
-int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, int form, hipStream_t stream);
+// scratch (optional): attention_bf3_split_floats(...) floats enable the key-split form for small batches (a second, merging launch)
+int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, int form, hipStream_t stream,
+                         float* scratch = nullptr, size_t scratch_floats = 0);
+size_t attention_bf3_split_floats(int batch, int n_heads, int l, int* nsplit_out);
 int launch_gemm_planes(const pf_conv_args& a, hipStream_t stream);   // called by launch_conv when a.a_planes
 // out = x + ff2(GeGLU(ff1(LayerNorm(x)))) for C = 256, hidden 1024, as one launch (mlp_fused_bf3.hip); w1 / w2 = bf16x3 packings
 int launch_mlp_fused(const float* x, int batch, int l, const float* gamma, const float* beta, float eps, const void* w1, const float* b1,

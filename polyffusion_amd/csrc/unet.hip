@@ -619,9 +619,14 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
       a.prologue = 3; a.sc = c.w(t.n1g); a.sh = c.w(t.n1b); a.mean = mu; a.rstd = rs;
       c.conv(a, PF_K_GEMM);
     }
+    // small batches (few query tiles, many key tiles each): key slices across workgroups + a merging launch, partial results in the temp region
+    int att_ns = 1;
+    const size_t att_sf = planes ? attention_bf3_split_floats(B, nh, hw, &att_ns) : 0;
+    float* att_scratch = att_sf ? c.talloc(att_sf) : nullptr;
     c.prof_begin(PF_K_ATTN, 4.0 * B * nh * (double)hw * hw * dh);
+    if (att_sf && c.u->opt[PF_OPT_ATTN_WIDE] != PF_OPT_ON) ++c.n_launch;   // the merge
     if (!c.dry && c.rc == PF_OK)
-      c.rc = planes ? launch_attention_bf3(qkv, nullptr, C, att, B, nh, hw, c.u->opt[PF_OPT_ATTN_WIDE], c.s)   // att as hi/lo planes for the to_out GEMM
+      c.rc = planes ? launch_attention_bf3(qkv, nullptr, C, att, B, nh, hw, c.u->opt[PF_OPT_ATTN_WIDE], c.s, att_scratch, att_sf)   // att as hi/lo planes for the to_out GEMM
                     : launch_attention(qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, att, C, B, nh, dh, hw, hw, c.s);
     c.prof_end();
     last_planes = planes && (i + 1 == L.tbs.size());
@@ -1148,6 +1153,13 @@ int pf_gn_finalize_tiles(const float* stats0, int tiles0, int c0, const float* s
 int pf_conv2d(const pf_conv_args* a, void* stream) {
   PF_REQUIRE(a, "pf_conv2d: null argument");
   return launch_conv(*a, (hipStream_t)stream);
+}
+size_t pf_attention_split_scratch_bytes(int batch, int n_heads, int l) {
+  return (batch > 0 && n_heads > 0 && l > 0) ? attention_bf3_split_floats(batch, n_heads, l, nullptr) * sizeof(float) : 0;
+}
+int pf_attention_bf16x3_split(const void* qkv_planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, void* scratch, size_t scratch_bytes,
+                              void* stream) {
+  return launch_attention_bf3(qkv_planes, o, ldo, o_planes, batch, n_heads, l, 0, (hipStream_t)stream, static_cast<float*>(scratch), scratch_bytes / sizeof(float));
 }
 int pf_attention_bf16x3(const void* qkv_planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, int form, void* stream) {
   return launch_attention_bf3(qkv_planes, o, ldo, o_planes, batch, n_heads, l, form, (hipStream_t)stream);

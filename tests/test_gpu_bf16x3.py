@@ -479,3 +479,44 @@ def test_groupnorm_finalize_inside_the_consumer(lib, B, H, W, c0, c1, cout, tile
     with pytest.raises(RuntimeError, match="fused GroupNorm"):
         run_conv(lib, sc=sc, sh=sh, out=out, gn_stats0=s0, gn_tiles0=tiles, gn_gamma=g, gn_beta=bt, gn_eps=1e-5, gn_groups=32,
                  **dict(kw, precision=0))
+
+
+@pytest.mark.parametrize("B,L", [(1, 1024), (2, 1024), (1, 512), (3, 1024)])
+def test_attention_key_split_form_small_batches(lib, B, L):
+    """pf_attention_bf16x3_split: at batch 1 / 2 the keys of every 128-query tile are walked by four workgroups and merged by a second launch
+    (online-softmax combination) - against torch, against the one-launch form, fp32 and plane outputs, bit-reproducible; a shape that fills
+    the chip (B = 3 at L = 1024 does not qualify) reports zero scratch and runs the one launch."""
+    H, c = 4, 256
+    x = rnd((B, L, c), 181) * 1.3 + 0.2
+    gamma, beta = 1 + 0.1 * rnd((c,), 182), 0.1 * rnd((c,), 183)
+    w = rnd((3 * c, c), 184, c ** -0.5) * 1.5
+    qkv = F.linear(F.layer_norm(x, (c,), gamma, beta), w)
+    q, k, v = (t.reshape(B, L, H, 64) for t in qkv.chunk(3, dim=-1))
+    att = (torch.einsum("bihd,bjhd->bhij", q, k) * 0.125).softmax(-1)
+    ref = torch.einsum("bhij,bjhd->bihd", att, v).reshape(B, L, c)
+    xd = dev(x)
+    mu, rs = torch.empty(B * L, device="cuda"), torch.empty(B * L, device="cuda")
+    st = _lib.current_stream()
+    _lib.check(lib.pf_ln_stats(xd.data_ptr(), B * L, c, 1e-5, mu.data_ptr(), rs.data_ptr(), st))
+    planes = torch.zeros(B * L * 3 * c, dtype=torch.float32, device="cuda")
+    run_conv(lib, x0=xd, c0=c, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, w), n=3 * c, prologue=3, sc=dev(gamma), sh=dev(beta), mean=mu, rstd=rs,
+             out=torch.empty(1, device="cuda"), ld_out=3 * c, precision=1, qkv_planes=planes)
+    need = int(lib.pf_attention_split_scratch_bytes(B, H, L))
+    assert (need > 0) == (B <= 2)
+    scratch = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
+    one = torch.empty(B, L, c, device="cuda")
+    _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), one.data_ptr(), c, None, B, H, L, 0, st))
+    out = torch.empty(B, L, c, device="cuda")
+    _lib.check(lib.pf_attention_bf16x3_split(planes.data_ptr(), out.data_ptr(), c, None, B, H, L, scratch.data_ptr(), need, st))
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max().item() < 3e-4
+    d = (out - one).abs().max().item()
+    assert d < 2e-5 and (need == 0) == (d == 0.0)          # merged partial sums: another summation order; no split: the same launch
+    op = torch.zeros(B * L * c, device="cuda")
+    _lib.check(lib.pf_attention_bf16x3_split(planes.data_ptr(), None, c, op.data_ptr(), B, H, L, scratch.data_ptr(), need, st))
+    pl = op.view(torch.bfloat16).float().view(2, B, L, c)
+    assert (pl[0] + pl[1] - out).abs().max().item() < 2e-5 * max(1.0, out.abs().max().item())
+    for _ in range(4):
+        o2 = torch.empty_like(out)
+        _lib.check(lib.pf_attention_bf16x3_split(planes.data_ptr(), o2.data_ptr(), c, None, B, H, L, scratch.data_ptr(), need, st))
+        assert torch.equal(o2, out)
