@@ -39,6 +39,20 @@ def test_bench_two_ranks():
     assert len(pr["all"]) == 2 and pr["min"] == min(pr["all"]) and pr["max"] == max(pr["all"]) and 0 < pr["max"] <= d["ms_per_step"] * 1.05
 
 
+def test_bench_eight_ranks_on_one_device():
+    """The shape the driver's scaling run has - `--gpus 8`, one rank per GPU - with all eight ranks on device 0 over gloo: rank / offset
+    bookkeeping for eight shards, the weight broadcast to seven receivers, barriers, max-over-ranks timing and the per-rank step times."""
+    out = torchrun(["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1", "--windows", "2", "--profile-steps", "0", "--fp32-steps", "0",
+                    "--small-batch-steps", "0"], 29649, nproc=8, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["devices_seen"] == [0] * 8 and d["config"]["global_batch"] == 128
+    assert len(d["per_rank_ms_per_step"]["all"]) == 8 and d["per_rank_ms_per_step"]["max"] <= d["ms_per_step"] * 1.05
+    assert abs(d["value"] - 8 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) / d["value"] < 1e-3 and "cpu_baseline" not in d
+
+
 def test_bench_bare_command_spawns_its_ranks():
     """`python bench.py --gpus 2` WITHOUT a launcher (how a driver that mirrors its 1-GPU command would call it): bench.py re-executes
     itself under torch.distributed.run, one rank per GPU, and still prints exactly one JSON line with both ranks in it."""
