@@ -23,6 +23,8 @@ Extra objects (see DESIGN.md "Measurement"):
                  bf16 matrix pipe, peak 2500/3 TFLOP/s fp32-equivalent): algorithmic FLOPs of its launches / their summed
                  duration, measured with hipEvents around every launch on the launch stream in a separate profiled pass.
   fp32_mode    - the same workload with exact fp32 MFMA (peak 157.3 TFLOP/s), printed beside the headline.
+  f16x3_mode   - the same workload in the fp16-split build of the library (libpfhip_f16.so: three fp16 MFMAs per product, fp32-class
+                 error), timed in windows alternating with bf16x3 windows, with both splits' distance to the f32 mode on one evaluation.
   cpu_baseline - the CPU oracle (same ATen ops as the reference) timed on this host's cores: one warm-up step, a thread sweep,
                  then the median of 3 steps at batch 16 with the best thread count; rank 0 and N == 1 only.
 """
@@ -59,9 +61,10 @@ BATCH = 16
 KIND_NAMES = ["conv3x3_mfma", "gemm_mfma", "attention", "gn_stats", "ln_stats", "small"]
 
 
-def build_model(params, rank, world):
-    """rank 0 generates + packs the weights; everyone else receives the packed blobs (RCCL broadcast)."""
-    unet = build_unet(params)
+def build_model(params, rank, world, x3=None):
+    """rank 0 generates + packs the weights; everyone else receives the packed blobs (RCCL broadcast).
+    x3="f16": the denoiser lives in the fp16-split build of the library (f16x3_mode leg)."""
+    unet = build_unet(params, x3=x3)
     chord_enc, _ = build_encoders(params)
     dev = torch.device("cuda", torch.cuda.current_device())
     if rank == 0:
@@ -219,7 +222,7 @@ def measure_traffic(precision):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--windows", "1", "--profile-steps", "0", "--no-cpu-baseline",
-             "--small-batch-steps", "0", "--fp32-steps", "0", "--no-pmc", "--precision", precision]
+             "--small-batch-steps", "0", "--fp32-steps", "0", "--f16x3-steps", "0", "--no-pmc", "--precision", precision]
     pat = "conv_bf3_kernel<" if precision == "bf16x3" else "conv_mfma_kernel<"
     tot, launches = {}, 0
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
@@ -451,6 +454,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--windows", type=int, default=5, help="back-to-back timed windows of --steps steps each; the median window is reported")
     ap.add_argument("--profile-steps", type=int, default=2, help="profiled steps for the roofline object (0 disables)")
+    ap.add_argument("--f16x3-steps", type=int, default=20, help="steps per window of the f16x3 leg (fp16-split build, alternating with bf16x3 windows; 0 disables)")
     ap.add_argument("--fp32-steps", type=int, default=10, help="steps of the exact-fp32-MFMA mode measured in the same run (0 disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not spawn the two rocprofv3 counter passes that measure roofline.traffic in the run")
@@ -627,6 +631,51 @@ def main():
                 fp32["conv3x3_frac_of_157"] = round(agg32[0][2] / (agg32[0][1] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
         unet.set_precision(args.precision)
         out["fp32_mode"] = fp32
+    if args.f16x3_steps > 0 and args.precision == "bf16x3" and _lib.X3_VARIANT == "":
+        # the fp16 split (libpfhip_f16.so) on the same workload: a second model instance in the other build of the library, same weights,
+        # same sampler state; windows alternate with bf16x3 windows so both see the same clocks (every rank runs it: barriers line up)
+        model16, _ = build_model(params, rank, world, x3="f16")
+        u16 = model16.ldm.eps_model
+        u16.set_precision("f16x3")
+        for o in args.option:
+            name, val = o.split("=")
+            u16.set_option(name, bool(int(val)))
+        s16 = SDFSampler(model16.ldm, seed=1234, sample_offset=lo)
+        prep16 = s16.prepare(cond)
+
+        def step16(x_t, step):
+            return s16.repaint_step(x_t, cond, step, zeros, zeros, prep=prep16)
+
+        x16 = x.clone()
+        for _ in range(3):
+            x16 = step16(x16, t_step)
+        wa, wb = [], []
+        for _ in range(max(1, args.secondary_windows)):
+            x, t_step, el_b, _, mhz_b = timed_loop(step_fn, x, t_step, args.f16x3_steps, probe)
+            x16, _, el_h, _, mhz_h = timed_loop(step16, x16, t_step, args.f16x3_steps, probe)
+            wb.append(el_b); wa.append((el_h, mhz_h))
+        assert torch.isfinite(x16).all(), "non-finite sample (f16x3)"
+        el_h, mhz_h = sorted(wa, key=lambda w: w[0])[len(wa) // 2]
+        el_b = sorted(wb)[len(wb) // 2]
+        f16 = {"steps_per_s": round(world * args.f16x3_steps / el_h, 4), "ms_per_step": round(el_h / args.f16x3_steps * 1e3, 4),
+               "steps": args.f16x3_steps, "windows": len(wa), "windows_ms_per_step": [round(w[0] / args.f16x3_steps * 1e3, 4) for w in wa],
+               "bf16x3_alternating_ms_per_step": round(el_b / args.f16x3_steps * 1e3, 4), "speed_vs_bf16x3": round(el_b / el_h, 4),
+               "sclk_mhz": mhz_h, "launches_per_step": u16.n_launches(BATCH, prepared=True) + 1,
+               "path_frac_of_833": round(f_eval * BATCH * args.f16x3_steps / el_h / (PEAK_ALGO["bf16x3"] * 1e12), 4)}
+        if rank == 0:
+            # one evaluation, three arithmetics, same inputs: distance of each split to the exact-fp32-MFMA mode, relative to max|eps|
+            xe = sampler.randn(shape, dev)
+            te = torch.full((BATCH,), 500, dtype=torch.long, device=dev)
+            unet.set_precision("f32")
+            e32 = unet(xe, te, cond).clone()
+            unet.set_precision("bf16x3")
+            eb, eh = unet(xe, te, cond), u16(xe, te, cond)
+            sc = e32.abs().max().item()
+            f16["eps_rel_diff_vs_f32_mode"] = {"bf16x3": float(f"{(eb - e32).abs().max().item() / sc:.3e}"), "f16x3": float(f"{(eh - e32).abs().max().item() / sc:.3e}")}
+            f16["vs_float64"] = ("tests/test_gpu_f16x3.py, B = 2 against the oracle in float64, relative to max|eps|: f32 mode 1.8e-6 / bf16x3 1.6e-5 / "
+                                 "f16x3 1.4e-6 on the synthetic weights, 1.7e-4 / 1.6e-3 / 1.3e-4 on the worst stressed net")
+        out["f16x3_mode"] = f16
+        del s16, prep16, u16, model16
     if rank == 0 and args.small_batch_steps > 0:
         out["small_batch"] = small_batch_lines(model, params, args.small_batch_steps, args.precision, args.secondary_windows, probe)
         out["config3"] = config3_line(model, params, 10, args.secondary_windows, probe)

@@ -250,6 +250,13 @@ int pf_encoder_forward(pf_encoder* e, const float* x, int batch, int n_step, flo
 enum { PF_PREC_F32 = 0, PF_PREC_BF16X3 = 1 };
 int pf_unet_set_precision(pf_unet* u, int precision);
 int pf_unet_get_precision(const pf_unet* u);
+/* Element type of the split: the library is built twice from the same sources.  libpfhip.so splits into bf16 pieces (8 + 8 mantissa
+ * bits, fp32's exponent range: "bf16x3", unit roundoff ~2^-18).  libpfhip_f16.so (-DPF_X3_F16) splits into fp16 pieces (11 + 11 bits,
+ * three v_mfma_f32_32x32x16_f16 per product: "f16x3", ~2^-22 - the error of the fp32 mode - at ~0.97 of bf16x3's speed), with fp16's
+ * range: activations must stay below 65504 in magnitude (weights below 255; they are stored times 2^8 and every epilogue undoes it).
+ * In that library every entry point and constant named bf16x3 means f16x3; weight packings and plane buffers of the two libraries are
+ * not interchangeable.  Returns 0 (bf16 pieces) or 1 (fp16 pieces). */
+int pf_x3_element(void);
 
 /* ---- per-op entry points (unit-testable kernels; same kernels the plan launches) ---------- */
 /* Host helper: torch weight [N, K, kh, kw] (kh=kw=1 or 3) -> packed [kh*kw][K/4][Npad][4], Npad = roundup(N,64). */

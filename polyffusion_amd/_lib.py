@@ -11,7 +11,28 @@ import os
 from typing import Optional
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpfhip.so")
+# The library exists in two builds of the same sources (csrc/pf_internal.h): libpfhip.so splits operands into bf16 pieces ("bf16x3"),
+# libpfhip_f16.so (`python -m polyffusion_amd.build --variant=f16`) into fp16 pieces ("f16x3": fp32-class error, ~3 % slower, fp16's range).
+# load() returns the process default - libpfhip.so unless PF_X3=f16 is set, which makes everything named "bf16x3" run as f16x3 (how the
+# whole GPU suite is run against the fp16 build); load("f16") returns the fp16 build explicitly (UNetModel.set_precision("f16x3")).
+X3_VARIANT = {"": "", "bf16": "", "f16": "f16"}.get(os.environ.get("PF_X3", ""), None)
+if X3_VARIANT is None:
+    raise RuntimeError(f"PF_X3={os.environ['PF_X3']!r}: expected 'bf16' (default) or 'f16'")
+
+
+def lib_path(variant: str = "") -> str:
+    return os.path.join(HERE, f"libpfhip_{variant}.so" if variant else "libpfhip.so")
+
+
+LIB_PATH = lib_path(X3_VARIANT)
+X3_WEIGHT_SCALE = 256.0 if X3_VARIANT == "f16" else 1.0     # what the default library's split packing multiplies weights by (PF_X3_WS)
+
+
+def x3_torch_dtype(variant: Optional[str] = None):
+    """Element type of the hi / lo planes the split-precision kernels exchange (tests decode planes with it)."""
+    import torch
+    return torch.float16 if (X3_VARIANT if variant is None else variant) == "f16" else torch.bfloat16
+
 
 c_float_p = C.POINTER(C.c_float)
 c_i64_p = C.POINTER(C.c_int64)
@@ -137,6 +158,7 @@ SIGNATURES = {
     "pf_pack_upfold_weight_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pf_unet_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_unet_get_precision": (C.c_int, [C.c_void_p]),
+    "pf_x3_element": (C.c_int, []),
     "pf_gn_scale_shift": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pf_ln_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -158,30 +180,35 @@ SIGNATURES = {
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
-_lib: Optional[C.CDLL] = None
+_libs: dict = {}
 
 
-def load() -> C.CDLL:
-    """dlopen libpfhip.so and attach prototypes.  Raises if the library has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(variant: Optional[str] = None) -> C.CDLL:
+    """dlopen the library (default build, or the named variant) and attach prototypes.  Raises if it has not been built.
+    Both builds can live in one process: they are opened RTLD_LOCAL and share nothing but the HIP runtime."""
+    v = X3_VARIANT if variant is None else variant
+    if v in _libs:
+        return _libs[v]
+    path = lib_path(v)
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m polyffusion_amd.build` "
+            f"{path} not found: the HIP extension is not built. Run `python -m polyffusion_amd.build{' --variant=' + v if v else ''}` "
             "(or __graft_entry__.build()). There is no CPU fallback for this path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    if lib.pf_x3_element() != (1 if v == "f16" else 0):
+        raise RuntimeError(f"{path}: built with the wrong split element type (pf_x3_element() = {lib.pf_x3_element()})")
+    _libs[v] = lib
     return lib
 
 
-def check(rc: int, what: str = "") -> int:
+def check(rc: int, what: str = "", lib: Optional[C.CDLL] = None) -> int:
+    """Raise on a negative return code, with the message of the library that produced it (`lib`: default build if omitted)."""
     if rc < 0:
-        msg = load().pf_last_error().decode("utf-8", "replace")
+        msg = (lib or load()).pf_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"libpfhip {what}: error {rc}: {msg}")
     return rc
 

@@ -10,6 +10,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["conv_mfma.hip", "conv_bf16x3.hip", "gemm_planes_bf3.hip", "mlp_fused_bf3.hip", "preattn_fused_bf3.hip", "attention.hip", "attention_bf3.hip", "norm_stats.hip", "small_kernels.hip", "encoders.hip", "comm.hip", "unet.hip"]
 LIB = os.path.join(HERE, "libpfhip.so")
+# variants: the same sources compiled with another element type for the split-precision kernels (csrc/pf_internal.h, PF_X3_F16);
+# objects get a suffix, the library another name, the stamp its own keys.  PF_X3=f16 in the environment selects it at load (_lib.py).
+VARIANTS = {"": [], "f16": ["-DPF_X3_F16"]}
+
+
+def lib_path(variant: str = "") -> str:
+    return os.path.join(HERE, f"libpfhip_{variant}.so" if variant else "libpfhip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + (["-DPF_TRACE"] if os.environ.get("PF_TRACE") else [])
 # per-file additions.  attention_bf3: the softmax of the 256-query kernel is dealt out between MFMAs one single-issue instruction at a
@@ -50,7 +57,7 @@ def _write_stamp(st: dict) -> None:
     os.replace(STAMP + ".new", STAMP)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
     """Compile what is not provably current.  `force` (or PF_FORCE_BUILD=1 in the environment) recompiles every translation
     unit.  Otherwise an object is reused only when the stamp file records, for it, the digest of the source + every header +
     the flags it would be compiled with now; the library likewise against the digests of its objects."""
@@ -59,11 +66,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + [os.path.join(HERE, "..", "include", "pfhip.h")]
     stamp = _read_stamp()
     objs, jobs, want = [], [], {}
-    for src in SOURCES:
-        s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+    sfx = f".{variant}" if variant else ""
+    lib, lib_key = lib_path(variant), os.path.basename(lib_path(variant))
+    for src0 in SOURCES:
+        s = os.path.join(CSRC, src0)
+        src = src0 + sfx                      # stamp key
+        o = os.path.join(CSRC, src0.replace(".hip", sfx + ".o"))
         objs.append(o)
-        flags = FLAGS + EXTRA_FLAGS.get(src, [])
+        flags = FLAGS + EXTRA_FLAGS.get(src0, []) + VARIANTS[variant]
         want[src] = _digest([s] + hdrs, flags)
         if force or not os.path.exists(o) or stamp.get(src) != want[src]:
             cmd = [HIPCC] + flags + ["-c", s, "-o", o]
@@ -71,6 +81,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 print(" ".join(cmd), flush=True)
             jobs.append((src, cmd))
     if jobs:   # the translation units are independent: compile them side by side
+        stamp = _read_stamp()                 # (another variant's build may have written since)
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
             rcs = list(ex.map(lambda j: subprocess.run(j[1]).returncode, jobs))
@@ -85,15 +96,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
     elif verbose:
         print(f"polyffusion_amd.build: {len(SOURCES)} objects current by content digest (PF_FORCE_BUILD=1 recompiles)", flush=True)
     lib_want = _digest(objs)
-    if force or jobs or not os.path.exists(LIB) or stamp.get("libpfhip.so") != lib_want:
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    if force or jobs or not os.path.exists(lib) or stamp.get(lib_key) != lib_want:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        stamp["libpfhip.so"] = lib_want
+        stamp[lib_key] = lib_want
         _write_stamp(stamp)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    for v in ([a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")] or [""]):
+        build(force="--force" in sys.argv, variant=v)

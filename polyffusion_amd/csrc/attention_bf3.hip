@@ -413,8 +413,15 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
       const f32x2 v = {v0, v1};
       phw[BUF][qf][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // hi = RNE bf16 pair (key 2j in the low half)
     } else if constexpr (ST == 1) {   // the float values of hi, rebuilt from the packed word
+#ifdef PF_X3_F16
+      // (spelled as instructions: hipcc 7.2 folds `(float)bit_cast<half2>(phw[..][j])[i]` to element j = 0's conversion for every j)
+      const unsigned w = phw[BUF][qf][j];
+      asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(th0[j8]) : "v"(w));
+      asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(th1[j8]) : "v"(w));
+#else
       th0[j8] = __uint_as_float(phw[BUF][qf][j] << 16);
       th1[j8] = __uint_as_float(phw[BUF][qf][j] & 0xffff0000u);
+#endif
     } else if constexpr (ST == 2) {
       th0[j8] = v0 - th0[j8];
       th1[j8] = v1 - th1[j8];

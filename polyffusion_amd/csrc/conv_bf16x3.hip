@@ -835,6 +835,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     }
     __syncthreads();            // the epilogue reuses this LDS for the statistics
   }
+  x3_unscale(acc);
   conv_epilogue<TH, TW, BN, FM, FN, NWM>(p, acc, b, oy0, ox0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem_all), kg == 0);
   TR();
 }
@@ -1004,28 +1005,38 @@ static inline unsigned short f2bf_rne(float f) {
 }
 static inline float bf2f(unsigned short h) { unsigned int u = (unsigned int)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-void pack_gemm_bf3(void* dst_, const float* src, int n_src, int K, int taps, int Npad, int n_off, const int* colmap) {
+bool pack_gemm_bf3(void* dst_, const float* src, int n_src, int K, int taps, int Npad, int n_off, const int* colmap) {
   unsigned short* dst = (unsigned short*)dst_;
+  bool fits = true;
   const int K8 = K / 8;
   for (int n = 0; n < n_src; ++n) {
     const int col = colmap ? colmap[n] : n_off + n;
     for (int k = 0; k < K; ++k)
       for (int t = 0; t < taps; ++t) {
         const float v = src[((size_t)n * K + k) * taps + t];
+#ifdef PF_X3_F16
+        const float vs = fminf(fmaxf(v * PF_X3_WS, -65504.f), 65504.f);
+        fits = fits && vs == v * PF_X3_WS;
+        const _Float16 fh = (_Float16)vs, fl = (_Float16)(vs - (float)fh);
+        unsigned short hi, lo;
+        memcpy(&hi, &fh, 2); memcpy(&lo, &fl, 2);
+#else
         const unsigned short hi = f2bf_rne(v);
         const unsigned short lo = f2bf_rne(v - bf2f(hi));
+#endif
         const size_t base = ((size_t)t * K8 + k / 8) * 2;
         dst[((base + 0) * Npad + col) * 8 + (k & 7)] = hi;
         dst[((base + 1) * Npad + col) * 8 + (k & 7)] = lo;
       }
   }
+  return fits;
 }
 
 
 // UpSample = nearest x2 then conv3x3 (ref:unet.py:236-238).  Output pixel (2y+py, 2x+px) only ever sees a 2x2 block of SOURCE
 // pixels: rows {y-1, y} with weights {w[0], w[1]+w[2]} for py = 0, rows {y, y+1} with {w[0]+w[1], w[2]} for py = 1 (columns
 // alike), so the layer is four 2x2 convolutions on the source grid - 16 taps in total instead of 4 x 9.
-void pack_upfold_bf3(void* dst, const float* src, int N, int K, int Npad) {
+bool pack_upfold_bf3(void* dst, const float* src, int N, int K, int Npad) {
   std::vector<float> f((size_t)N * K * 16);
   static const int lo[2][2] = {{0, 1}, {0, 2}}, hi[2][2] = {{0, 2}, {1, 2}};   // [parity][tap] -> kernel index range [lo, hi]
   for (size_t nk = 0; nk < (size_t)N * K; ++nk) {
@@ -1040,7 +1051,7 @@ void pack_upfold_bf3(void* dst, const float* src, int N, int K, int Npad) {
             f[nk * 16 + (py * 2 + px) * 4 + dy * 2 + dx] = (float)acc;
           }
   }
-  pack_gemm_bf3(dst, f.data(), N, K, 16, Npad, 0, nullptr);
+  return pack_gemm_bf3(dst, f.data(), N, K, 16, Npad, 0, nullptr);
 }
 
 }  // namespace pf

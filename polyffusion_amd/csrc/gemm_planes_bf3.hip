@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
   #pragma unroll
   for (int i = 0; i < FN; ++i) asm volatile("" ::"v"(bh[i]), "v"(bl[i]));
   __syncthreads();
+  x3_unscale(acc);
   conv_epilogue<1, BM, BN, FM, FN, 2>(p, acc, b, 0, ox0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(smem_raw));
 }
 

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
     if constexpr (i < 12) {
       constexpr int e = 4 * q + i / 3, st = i % 3;
       if constexpr (st == 0) {          // gelu_erf_f / erf_as_f of conv_common.h, cut in three
-        tz[e] = gg[e] + bg;
+        tz[e] = PF_X3_UNSCALE(gg[e]) + bg;
         const float ax = fabsf(tz[e] * 0.70710678118654752440f);
         tt[e] = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
         tq[e] = ax;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
       } else {
         const float y = 1.0f - tt[e] * __expf(-tq[e] * tq[e]);
         const float er = copysignf(y, tz[e] * 0.70710678118654752440f);
-        hq[q][e & 3] = (gv[e] + bv) * (0.5f * tz[e] * (1.0f + er));
+        hq[q][e & 3] = (PF_X3_UNSCALE(gv[e]) + bv) * (0.5f * tz[e] * (1.0f + er));
       }
     } else if constexpr (i == 12 || i == 13) {   // quad_transpose stage 1 (conv_common.h), one register pair per piece
       constexpr int lo = (i - 12) * 2;            // pair (0,1) then (2,3)
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
         for (int fn = 0; fn < 4; ++fn) {
           f32x4 v = {acc2[0][fn][4 * q], acc2[0][fn][4 * q + 1], acc2[0][fn][4 * q + 2], acc2[0][fn][4 * q + 3]};
           quad_transpose(v, lane);
-          v = v + (b4[fn] + r4[fn]);        // acc + (bias + residual): the order of conv_epilogue's plane-pair path, which this replaces
+          v = PF_X3_UNSCALE(v) + (b4[fn] + r4[fn]);        // acc + (bias + residual): the order of conv_epilogue's plane-pair path, which this replaces
           const bf16x4_m hi = __builtin_convertvector(v, bf16x4_m);
           const bf16x4_m lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4_m);
           unsigned char* d = sA + (wn * 4 + fn) * CH_B + row * 64 + (((cq >> 3) ^ ((row >> 2) & 3)) * 16) + ((cq >> 2) & 1) * 8;
@@ -450,6 +450,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
 #undef SB
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
+  x3_unscale(acc2);
   conv_epilogue<1, BM, C, 1, 4, 2>(p, acc2, b, 0, ox0, 0, wm, wn, lane, tid, reinterpret_cast<float*>(sR));
 }
 

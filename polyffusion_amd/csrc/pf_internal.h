@@ -52,8 +52,9 @@ void conv_tile_shape(const pf_conv_args& a, int tile, int* th, int* tw);
 int conv_stats_tiles(const pf_conv_args& a);
 int conv_ksplit(const pf_conv_args& a);                           // K-split factor this launch uses (1 = none); needs a.splitk_ws
 size_t conv_splitk_ws_bytes(const pf_conv_args& a);              // scratch wanted for the split (0 = would not split)                      // per-sample tiles emitted into stats_out
-void pack_gemm_bf3(void* dst, const float* src, int n_src, int K, int taps, int Npad, int n_off, const int* colmap);
-void pack_upfold_bf3(void* dst, const float* src, int N, int K, int Npad);   // UpSample conv weight -> 4 parities x 4 taps
+// both return false when a weight does not fit the split's element type (fp16 build: |w| * 2^8 > 65504; the packing then holds the clamped value)
+bool pack_gemm_bf3(void* dst, const float* src, int n_src, int K, int taps, int Npad, int n_off, const int* colmap);
+bool pack_upfold_bf3(void* dst, const float* src, int N, int K, int Npad);   // UpSample conv weight -> 4 parities x 4 taps
 
 int launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                      int batch, int n_heads, int d_head, int lq, int lk, hipStream_t stream);
@@ -141,3 +142,32 @@ int launch_txt_frontend(const float* pr, const float* w, const float* bias, floa
                         hipStream_t s);
 
 }  // namespace pf
+
+// ---- element type of the split-precision ("x3") kernels ---------------------------------------------------------------------------------
+// The default build splits every operand into two bf16 pieces (8 + 8 mantissa bits, fp32's exponent range).  -DPF_X3_F16 compiles the very
+// same kernels with fp16 pieces (11 + 11 bits, three v_mfma_f32_32x32x16_f16 per product at the same rate): ~16x less rounding error per
+// product, paid for with fp16's range - |activation| must stay below 65504 and pieces below 6e-5 lose bits (fp16 subnormals ARE honoured by
+// the matrix pipe, tools/micro/f16x3_probe.hip).  Weights are small numbers (|w| ~ 0.03 puts the lo piece deep in the subnormals), so that
+// build packs them times PF_X3_WS = 2^8 and every epilogue takes its accumulators times 2^-8 - exact, and folded into the bias add as an fma.
+// The element type is spelled __bf16 throughout the kernels; the f16 build renames it here, after every system header has been read.
+#ifdef PF_X3_F16
+#define __bf16 _Float16
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define PF_X3_WS 256.0f
+#define PF_X3_WS_INV 0.00390625f
+#define PF_X3_UNSCALE(a) ((a) * PF_X3_WS_INV)
+#else
+#define PF_X3_WS 1.0f
+#define PF_X3_WS_INV 1.0f
+#define PF_X3_UNSCALE(a) (a)
+#endif
+// accumulator tile -> true units (a no-op in the bf16 build)
+template <int FM, int FN>
+__device__ __forceinline__ void x3_unscale(f32x16 (&acc)[FM][FN]) {
+#ifdef PF_X3_F16
+#pragma unroll
+  for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = acc[fm][fn] * PF_X3_WS_INV;
+#endif
+}

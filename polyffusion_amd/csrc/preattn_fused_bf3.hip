@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
       for (int fn = 0; fn < 4; ++fn) {
         f32x4 t = {acc[0][fn][4 * q], acc[0][fn][4 * q + 1], acc[0][fn][4 * q + 2], acc[0][fn][4 * q + 3]};
         quad_transpose(t, lane);
-        t += b4[fn];
+        t = PF_X3_UNSCALE(t) + b4[fn];
         const int slot = (wn * 128 + fn * 32 + cq) >> 2;
         *reinterpret_cast<f32x4*>(sY + row * C + ((slot ^ ((row & 3) << 2)) << 2)) = t;
       }
@@ -274,6 +274,7 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
       for (int fn = 0; fn < 4; ++fn) {
         f32x4 t = {acc[0][fn][4 * q], acc[0][fn][4 * q + 1], acc[0][fn][4 * q + 2], acc[0][fn][4 * q + 3]};
         quad_transpose(t, lane);
+        t = PF_X3_UNSCALE(t);
         const bf16x4_p hi = __builtin_convertvector(t, bf16x4_p);
         const bf16x4_p lo = __builtin_convertvector(t - __builtin_convertvector(hi, f32x4), bf16x4_p);
         *reinterpret_cast<bf16x4_p*>(pr + fn * 32) = hi;
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
   TRP();
   gemm_pass(g_qkv, 3 * C, 2 * C);                       // V: V^T [head][d][token] runs along the tokens - conv_epilogue's transposing
   // writer, staged through the planes + ring regions (both idle now: 128 KB for its 69.6 KB)
+  x3_unscale(acc);
   conv_epilogue<1, BM, C, 1, 4, 2>(p, acc, b, 0, ox0, 2 * C, wm, wn, lane, tid, reinterpret_cast<float*>(sA));
   TRP();
 #undef FRAGS_READY

@@ -327,24 +327,27 @@ static inline int geglu_col(int n, int inner) {  // torch row n of ff.net.0.proj
   return 64 * (j / 32) + (n < inner ? 0 : 32) + (j % 32);
 }
 
+// (fp16 build only: bf16 pieces have fp32's range)
+#define X3_RANGE_MSG "%s: a weight exceeds what this library's fp16 split packing holds (|w| <= 255.8; weights are stored times 2^8): load the checkpoint with the default library (bf16x3 / f32)"
 static int pack_one(const ParamSpec& ps, const float* src, float* blob) {
   size_t numel = 1; for (auto s : ps.shape) numel *= (size_t)s;
+  bool fits = true;
   for (const Dest& d : ps.dests) {
     float* dst = blob + d.off;
     switch (d.kind) {
       case D_RAW: memcpy(dst, src, numel * sizeof(float)); break;
       case D_GEMM:
         pack_gemm(dst, src, d.N, d.K, d.taps, d.Npad, d.n_off);
-        if (d.K % 8 == 0) pack_gemm_bf3(dst + (size_t)d.taps * d.K * d.Npad, src, d.N, d.K, d.taps, d.Npad, d.n_off, nullptr);
+        if (d.K % 8 == 0) fits = pack_gemm_bf3(dst + (size_t)d.taps * d.K * d.Npad, src, d.N, d.K, d.taps, d.Npad, d.n_off, nullptr) && fits;
         break;
-      case D_UPFOLD: pack_upfold_bf3(dst, src, d.N, d.K, d.Npad); break;
+      case D_UPFOLD: fits = pack_upfold_bf3(dst, src, d.N, d.K, d.Npad) && fits; break;
       case D_GEGLU_W: {
         const int inner = d.N / 2;
         for (int n = 0; n < d.N; ++n)
           for (int k = 0; k < d.K; ++k) dst[((size_t)(k / 4) * d.Npad + geglu_col(n, inner)) * 4 + (k & 3)] = src[(size_t)n * d.K + k];
         std::vector<int> cm(d.N);
         for (int n = 0; n < d.N; ++n) cm[n] = geglu_col(n, inner);
-        pack_gemm_bf3(dst + (size_t)d.K * d.Npad, src, d.N, d.K, 1, d.Npad, 0, cm.data());
+        fits = pack_gemm_bf3(dst + (size_t)d.K * d.Npad, src, d.N, d.K, 1, d.Npad, 0, cm.data()) && fits;
         break;
       }
       case D_GEGLU_B: {
@@ -359,7 +362,7 @@ static int pack_one(const ParamSpec& ps, const float* src, float* blob) {
         break;
     }
   }
-  return PF_OK;
+  return fits ? PF_OK : PF_EINVAL;
 }
 
 // ---- forward ----
@@ -933,7 +936,7 @@ int pf_unet_pack_param(pf_unet* u, const char* key, const float* src, const int6
     for (int d = 0; d < ndim; ++d) got += std::to_string(shape[d]) + ",";
     return set_error(PF_EINVAL, "size mismatch for '%s': expected [%s] got [%s]", key, want.c_str(), got.c_str());
   }
-  pack_one(ps, src, (float*)host_blob);
+  if (pack_one(ps, src, (float*)host_blob) != PF_OK) return set_error(PF_EINVAL, X3_RANGE_MSG, key);
   ps.packed = true;
   return PF_OK;
 }
@@ -1071,6 +1074,13 @@ int pf_unet_set_precision(pf_unet* u, int precision) {
   return PF_OK;
 }
 int pf_unet_get_precision(const pf_unet* u) { return u ? u->precision : -1; }
+int pf_x3_element(void) {
+#ifdef PF_X3_F16
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 int pf_unet_set_profiling(pf_unet* u, int enabled) {
   PF_REQUIRE(u, "null handle");
@@ -1102,7 +1112,7 @@ int pf_pack_gemm_weight(const float* w, int n, int k, int taps, float* dst) {
 int pf_pack_gemm_weight_bf16x3(const float* w, int n, int k, int taps, void* dst) {
   PF_REQUIRE(w && dst && n > 0 && k > 0 && k % 8 == 0 && (taps == 1 || taps == 9), "pf_pack_gemm_weight_bf16x3: bad arguments");
   memset(dst, 0, pf_unet::gemm_floats(taps, k, n) * sizeof(float));
-  pack_gemm_bf3(dst, w, n, k, taps, (n + 63) / 64 * 64, 0, nullptr);
+  PF_REQUIRE(pack_gemm_bf3(dst, w, n, k, taps, (n + 63) / 64 * 64, 0, nullptr), X3_RANGE_MSG, "pf_pack_gemm_weight_bf16x3");
   return PF_OK;
 }
 
@@ -1113,7 +1123,7 @@ int pf_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batc
 }
 int pf_pack_upfold_weight_bf16x3(const float* w, int n, int k, void* dst) {
   PF_REQUIRE(w && dst && n > 0 && k > 0 && k % 8 == 0, "pack_upfold: bad arguments");
-  pack_upfold_bf3(dst, w, n, k, (n + 63) / 64 * 64);
+  PF_REQUIRE(pack_upfold_bf3(dst, w, n, k, (n + 63) / 64 * 64), X3_RANGE_MSG, "pf_pack_upfold_weight_bf16x3");
   return PF_OK;
 }
 int pf_prmat2c_durations(const float* prmat2c, int n, int steps, int custom_round, int32_t* dur, void* stream) {

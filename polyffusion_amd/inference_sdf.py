@@ -231,17 +231,18 @@ class Experiments:
 
 
 # --------------------------------------------------------------------------------------------- assembly
-def build_unet(params, device=None) -> UNetModel:
+def build_unet(params, device=None, x3=None) -> UNetModel:
+    """`x3="f16"`: the model lives in the fp16-split build of the library (its split mode is "f16x3", UNetModel.__init__)."""
     return UNetModel(in_channels=params.in_channels, out_channels=params.out_channels, channels=params.channels,
                      attention_levels=params.attention_levels, n_res_blocks=params.n_res_blocks,
                      channel_multipliers=params.channel_multipliers, n_heads=params.n_heads, tf_layers=params.tf_layers,
-                     d_cond=params.d_cond, img_h=params.img_h, img_w=params.img_w, device=device)
+                     d_cond=params.d_cond, img_h=params.img_h, img_w=params.img_w, device=device, x3=x3)
 
 
 PRECISION_PROBE_TOL = 3e-4
 
 
-def pick_precision(unet: UNetModel, cond: torch.Tensor, tol: float = PRECISION_PROBE_TOL, n_steps: int = 1000, seed: int = 0):
+def pick_precision(unet: UNetModel, cond: torch.Tensor, tol: Optional[float] = None, n_steps: int = 1000, seed: int = 0):
     """``--precision auto``: choose the arithmetic mode by MEASURING this network.  bf16x3 (three bf16 MFMAs per product, unit
     roundoff ~2^-18) is ~3x faster than the exact-fp32-MFMA mode and sits 5e-5 from the reference on ordinarily-conditioned
     weights, but every rounding error is amplified by the network's conditioning - fp32's too - and on badly-scaled weights the
@@ -250,6 +251,7 @@ def pick_precision(unet: UNetModel, cond: torch.Tensor, tol: float = PRECISION_P
     ``max|eps_bf16x3 - eps_f32| <= tol * max|eps_f32|`` (default 3e-4: a third of the contract).  Sets the mode on ``unet`` and
     returns ``(mode, measured ratio)``.  Cost: two evaluations of a loop that runs 50-1000."""
     lib = _lib.load()
+    tol = PRECISION_PROBE_TOL if tol is None else tol
     n = 3
     x = torch.empty(n, unet.cfg.in_channels, unet.img_h, unet.img_w, dtype=torch.float32, device=cond.device)
     _lib.check(lib.pf_randn(x.data_ptr(), x.numel(), int(seed) + 0x5eed, 0, 0, _lib.current_stream()), "pf_randn")
@@ -257,11 +259,11 @@ def pick_precision(unet: UNetModel, cond: torch.Tensor, tol: float = PRECISION_P
     c = cond[torch.arange(n, device=cond.device) % cond.shape[0]].contiguous()
     unet.set_precision("f32")
     ref = unet(x, t, c).clone()
-    unet.set_precision("bf16x3")
-    got = unet(x, t, c)
+    unet.set_precision(unet.split_mode)     # "bf16x3", or "f16x3" for a model built in the fp16-split library (where the probe mostly
+    got = unet(x, t, c)                     # guards fp16's range: an activation beyond 65504 shows up as a non-finite result)
     scale = ref.abs().max().item()
     ratio = float("inf") if not (scale > 0 and bool(torch.isfinite(got).all())) else (got - ref).abs().max().item() / scale
-    mode = "bf16x3" if ratio <= tol else "f32"
+    mode = unet.split_mode if ratio <= tol else "f32"
     unet.set_precision(mode)
     return mode, ratio
 
@@ -286,11 +288,11 @@ def build_pnotree_encoder(params, device=None):
     return PianoTreeEncoder(max_simu_note=20, device=device) if params.cond_type == "pnotree" else None
 
 
-def synthetic_model(params, seed: int = 0, device=None) -> Polyffusion_SDF:
+def synthetic_model(params, seed: int = 0, device=None, x3=None) -> Polyffusion_SDF:
     """Whole model with deterministic synthetic weights (same generator as the golden vectors)."""
     from .arch import UNetConfig
     from .weights import synth_chord_encoder_state, synth_texture_encoder_state, synth_unet_state
-    unet = build_unet(params, device)
+    unet = build_unet(params, device, x3)
     unet.load_state_dict(synth_unet_state(UNetConfig.from_params(params), seed))
     chord_enc, txt_enc = build_encoders(params, device)
     if chord_enc is not None:
@@ -373,9 +375,11 @@ def make_parser() -> ArgumentParser:
                    "db_pos_filter, chord - what get_data_for_single_midi / the POP909 .npz files hold): its 8-bar segments supply the "
                    "chord / texture conditions and the image to inpaint (ref:inference_sdf.py:599-610 via data/datasample.py)")
     p.add_argument("--bar_list", help="bars to inpaint for --inpaint_type bars, comma separated")
-    p.add_argument("--precision", choices=["auto", "f32", "bf16x3"], default="auto", help="arithmetic of the denoiser's contractions: f32 = exact "
-                   "fp32 MFMA; bf16x3 = error-compensated bf16 split (about 3x faster, 5e-5 from the reference on ordinarily-conditioned weights); "
-                   "auto (default) = evaluate both once on this checkpoint and keep bf16x3 only if they agree to 3e-4 of the output scale")
+    p.add_argument("--precision", choices=["auto", "f32", "bf16x3", "f16x3", "auto-f16x3"], default="auto", help="arithmetic of the denoiser's "
+                   "contractions: f32 = exact fp32 MFMA; bf16x3 = error-compensated bf16 split (about 3x faster, 5e-5 from the reference on "
+                   "ordinarily-conditioned weights); f16x3 = the same split in fp16 pieces (libpfhip_f16.so: fp32-class error at ~0.97 of bf16x3's "
+                   "speed, activations must stay below 65504); auto (default) = evaluate f32 and bf16x3 once on this checkpoint and keep bf16x3 "
+                   "only if they agree to 3e-4 of the output scale; auto-f16x3 = the same probe for f16x3 (it catches a range overflow)")
     p.add_argument("--hip_graph", action="store_true", help="capture one reverse step as a hipGraph and replay it (same results; "
                    "removes the host-side launch cost that bounds small batches, e.g. the batch-1 runs of --autoreg)")
     return p
@@ -416,7 +420,7 @@ def load_model(params, args, rank: int = 0, world: int = 1) -> Polyffusion_SDF:
     weights) and repacks it into the kernel-side blobs; with world > 1 the other ranks receive the packed blobs by ONE
     broadcast each (RCCL over xGMI) and never touch the file system - SURVEY.md 8e."""
     from . import _lib, dist as pfdist
-    unet = build_unet(params)
+    unet = build_unet(params, x3="f16" if getattr(args, "precision", None) in ("f16x3", "auto-f16x3") else None)
     chord_enc, txt_enc = build_encoders(params)
     parts = [("unet", unet, unet.weight_bytes())]
     if chord_enc is not None:
@@ -642,11 +646,27 @@ def main(argv=None):
         cond, cond_concat = cond[:n], cond_concat[:n]
         cond_mid = None if cond_mid is None else cond_mid[:n]
         orig, mask = (None if v is None else v[:n] for v in (orig, mask))
-    if args.precision == "auto":
-        mode, ratio = pick_precision(model.ldm.eps_model, cond.reshape(-1, *cond.shape[-2:]), n_steps=params.n_steps, seed=seed)
-        mode = ["f32", "bf16x3"][pfdist.broadcast_int(int(mode == "bf16x3"))]        # one decision for all ranks (rank 0's)
-        model.ldm.eps_model.set_precision(mode)
-        say(f"precision: {mode} (bf16x3 vs f32 on probe inputs: {ratio:.1e} of the output scale, threshold {PRECISION_PROBE_TOL:.0e})")
+    if args.precision in ("auto", "auto-f16x3"):
+        def probe(mdl):
+            split = mdl.ldm.eps_model.split_mode
+            mode, ratio = pick_precision(mdl.ldm.eps_model, cond.reshape(-1, *cond.shape[-2:]), n_steps=params.n_steps, seed=seed)
+            mode = ["f32", split][pfdist.broadcast_int(int(mode == split))]        # one decision for all ranks (rank 0's)
+            mdl.ldm.eps_model.set_precision(mode)
+            say(f"precision: {mode} ({split} vs f32 on probe inputs: {ratio:.1e} of the output scale, threshold {PRECISION_PROBE_TOL:.0e})")
+            return mode
+        if probe(model) == "f32" and args.precision == "auto":
+            # bf16x3 does not hold this checkpoint to the contract: before paying 3x for the fp32 mode, try the fp16 split (22 mantissa bits per
+            # product instead of 16, ~3 % slower than bf16x3) - the same weights loaded into the other build of the library, the same probe
+            import copy
+            args16 = copy.copy(args)
+            args16.precision = "auto-f16x3"
+            try:
+                model16 = load_model(params, args16, rank, world)
+            except (RuntimeError, SystemExit) as e:      # e.g. a weight beyond the fp16 packing's range
+                say(f"f16x3 not available for this checkpoint ({e}); staying with f32")
+                model16 = None
+            if model16 is not None and probe(model16) == "f16x3":
+                model = model16
     else:
         model.ldm.eps_model.set_precision(args.precision)
     S, B = args.num_generate, cond.shape[0]

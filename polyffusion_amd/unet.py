@@ -26,12 +26,19 @@ class UNetModel:
     def __init__(self, *, in_channels: int, out_channels: int, channels: int, n_res_blocks: int,
                  attention_levels: Iterable[int], channel_multipliers: Iterable[int], n_heads: int,
                  tf_layers: int = 1, d_cond: int = 768, img_h: int = 128, img_w: int = 128,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, x3: Optional[str] = None):
+        """`x3`: which build of the library this model lives in - None: the process default (libpfhip.so, bf16 pieces, unless PF_X3
+        says otherwise); "f16": libpfhip_f16.so, whose split mode is "f16x3" (include/pfhip.h pf_x3_element).  Weights are packed by, and
+        for, that library; a model never changes library."""
         self.cfg = UNetConfig(in_channels, out_channels, channels, n_res_blocks, tuple(attention_levels),
                               tuple(channel_multipliers), n_heads, tf_layers, d_cond)
         self.img_h, self.img_w = int(img_h), int(img_w)
         self.channels = channels
-        self._lib = _lib.load()
+        self.x3 = x3
+        self._lib = _lib.load(x3)
+        # name of the split mode: "f16x3" for a model asked to live in the fp16 build; a model in the process default keeps "bf16x3"
+        # (also under PF_X3=f16, which exists to run unchanged callers against the other build)
+        self._split_name = "f16x3" if x3 == "f16" else "bf16x3"
         c = _lib.UNetCfg()
         c.in_channels, c.out_channels, c.channels, c.n_res_blocks = in_channels, out_channels, channels, n_res_blocks
         c.n_attention_levels = len(self.cfg.attention_levels)
@@ -42,7 +49,7 @@ class UNetModel:
             c.channel_multipliers[i] = v
         c.n_heads, c.tf_layers, c.d_cond, c.img_h, c.img_w = n_heads, tf_layers, d_cond, self.img_h, self.img_w
         h = C.c_void_p()
-        _lib.check(self._lib.pf_unet_create(C.byref(c), C.byref(h)), "pf_unet_create")
+        self._check(self._lib.pf_unet_create(C.byref(c), C.byref(h)), "pf_unet_create")
         self._h = h
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()) \
             if torch.cuda.is_available() else None
@@ -50,6 +57,9 @@ class UNetModel:
         self._blob_dev: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
         self._ws_key = (0, 0, 0)
+
+    def _check(self, rc: int, what: str = "") -> int:
+        return _lib.check(rc, what, self._lib)
 
     def __del__(self):
         try:
@@ -66,7 +76,7 @@ class UNetModel:
         shape = (C.c_int64 * 4)()
         nd = C.c_int()
         for i in range(self._lib.pf_unet_n_params(self._h)):
-            _lib.check(self._lib.pf_unet_param_info(self._h, i, buf, 256, shape, C.byref(nd)))
+            self._check(self._lib.pf_unet_param_info(self._h, i, buf, 256, shape, C.byref(nd)))
             out[buf.value.decode()] = tuple(int(shape[d]) for d in range(nd.value))
         return out
 
@@ -80,7 +90,7 @@ class UNetModel:
             rc = self._lib.pf_unet_pack_param(self._h, key.encode(), t.data_ptr(), shape, t.dim(), blob.data_ptr())
             if rc == -2 and not strict:
                 continue
-            _lib.check(rc, f"load_state_dict({key})")
+            self._check(rc, f"load_state_dict({key})")
         buf = C.create_string_buffer(256)
         missing = self._lib.pf_unet_pack_missing(self._h, buf, 256)
         if missing:
@@ -96,7 +106,7 @@ class UNetModel:
         assert blob_dev.is_cuda and blob_dev.dtype == torch.float32 and blob_dev.numel() * 4 == self.weight_bytes()
         self._blob_dev = blob_dev
         self.device = blob_dev.device
-        _lib.check(self._lib.pf_unet_bind_weights(self._h, blob_dev.data_ptr()), "pf_unet_bind_weights")
+        self._check(self._lib.pf_unet_bind_weights(self._h, blob_dev.data_ptr()), "pf_unet_bind_weights")
 
     def load_state_dict(self, state: Mapping[str, object], strict: bool = True):
         """Reference-compatible weight ingestion (keys relative to ``eps_model``)."""
@@ -132,7 +142,7 @@ class UNetModel:
             out = torch.empty(n_rows, w, dtype=torch.float32, device=self.device)
         assert out.shape == (n_rows, w) and out.is_contiguous()
         scratch = torch.empty(n_rows * 4 * self.cfg.channels, dtype=torch.float32, device=self.device)
-        _lib.check(self._lib.pf_unet_prepare_time(self._h, n_rows, out.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,
+        self._check(self._lib.pf_unet_prepare_time(self._h, n_rows, out.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,
                                                   _lib.current_stream()), "pf_unet_prepare_time")
         return out
 
@@ -152,7 +162,7 @@ class UNetModel:
             out = torch.empty(B, w, dtype=torch.float32, device=cond.device)
         assert out.shape == (B, w) and out.is_contiguous()
         scratch = torch.empty(B * w, dtype=torch.float32, device=cond.device)
-        _lib.check(self._lib.pf_unet_prepare_cond(self._h, cond.data_ptr(), B, out.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,
+        self._check(self._lib.pf_unet_prepare_cond(self._h, cond.data_ptr(), B, out.data_ptr(), scratch.data_ptr(), scratch.numel() * 4,
                                                   _lib.current_stream()), "pf_unet_prepare_cond")
         return out
 
@@ -201,7 +211,7 @@ class UNetModel:
                 assert n_cond == 1 and cross_bias.shape[0] == B and cross_bias.is_contiguous() and cross_bias.device == x.device
                 prep.cross_bias = cross_bias.data_ptr()
         fn = self._lib.pf_unet_forward_cfg if shared_x else self._lib.pf_unet_forward_prepared
-        _lib.check(fn(self._h, x.data_ptr(), t.data_ptr(), cond.data_ptr(), B, n_cond, None if prep is None else C.byref(prep), out.data_ptr(),
+        self._check(fn(self._h, x.data_ptr(), t.data_ptr(), cond.data_ptr(), B, n_cond, None if prep is None else C.byref(prep), out.data_ptr(),
                       ws.data_ptr(), ws.numel(), _lib.current_stream()), "pf_unet_forward")
         return out
 
@@ -209,14 +219,23 @@ class UNetModel:
 
     # ---- arithmetic mode ------------------------------------------------------------------------
     def set_precision(self, mode: str):
-        """"f32" (exact fp32 MFMA) or "bf16x3" (error-compensated split on the bf16 matrix pipe)."""
-        code = {"f32": 0, "bf16x3": 1}[mode]
-        _lib.check(self._lib.pf_unet_set_precision(self._h, code), "pf_unet_set_precision")
+        """"f32" (exact fp32 MFMA) or this model's split mode: "bf16x3" (error-compensated split on the bf16 matrix pipe), or "f16x3"
+        (the same on the fp16 pipe) for a model constructed with x3="f16"."""
+        if mode not in ("f32", self._split_name):
+            raise ValueError(f"precision {mode!r}: this model supports 'f32' and {self._split_name!r} "
+                             "(the split element type is chosen at construction: UNetModel(..., x3='f16') for f16x3)")
+        code = 0 if mode == "f32" else 1
+        self._check(self._lib.pf_unet_set_precision(self._h, code), "pf_unet_set_precision")
         return self
 
     @property
+    def split_mode(self) -> str:
+        """Name of this model's split-precision mode: "bf16x3", or "f16x3" for a model constructed with x3="f16"."""
+        return self._split_name
+
+    @property
     def precision(self) -> str:
-        return ["f32", "bf16x3"][self._lib.pf_unet_get_precision(self._h)]
+        return ["f32", self._split_name][self._lib.pf_unet_get_precision(self._h)]
 
     # ---- plan options (which of two equivalent kernel forms the plan launches; include/pfhip.h PF_OPT_*) --------
     _OPTS = {"mlp_fused": _lib.OPT_MLP_FUSED, "attn_wide": _lib.OPT_ATTN_WIDE, "conv_t16": _lib.OPT_CONV_T16, "conv_pp": _lib.OPT_CONV_PP, "pre_fused": _lib.OPT_PRE_FUSED}
@@ -224,7 +243,7 @@ class UNetModel:
     def set_option(self, name: str, value: Optional[bool]):
         """``None`` = automatic (the default), ``False`` / ``True`` = never / always (where the form exists)."""
         v = _lib.OPT_AUTO if value is None else int(bool(value))
-        _lib.check(self._lib.pf_unet_set_option(self._h, self._OPTS[name], v), "pf_unet_set_option")
+        self._check(self._lib.pf_unet_set_option(self._h, self._OPTS[name], v), "pf_unet_set_option")
         return self
 
     def get_option(self, name: str) -> Optional[bool]:
@@ -237,14 +256,14 @@ class UNetModel:
 
     # ---- profiling ------------------------------------------------------------------------------
     def set_profiling(self, on: bool):
-        _lib.check(self._lib.pf_unet_set_profiling(self._h, int(on)))
+        self._check(self._lib.pf_unet_set_profiling(self._h, int(on)))
 
     def read_profile(self) -> List[Tuple[int, float, float]]:
         cap = 4096
         kind = (C.c_int * cap)()
         ms = (C.c_float * cap)()
         fl = (C.c_double * cap)()
-        n = _lib.check(self._lib.pf_unet_profile_read(self._h, kind, ms, fl, cap))
+        n = self._check(self._lib.pf_unet_profile_read(self._h, kind, ms, fl, cap))
         return [(kind[i], ms[i], fl[i]) for i in range(n)]
 
     def n_launches(self, batch: int, n_cond: int = 1, prepared: bool = False, shared_x: bool = False) -> int:

@@ -37,6 +37,34 @@ def test_header_symbols_exported_and_bound(lib):
     assert lib.pf_version() >= 100
 
 
+def test_both_builds_of_the_library_load_side_by_side_and_say_which_they_are(lib):
+    """libpfhip.so (bf16 pieces) and libpfhip_f16.so (fp16 pieces, -DPF_X3_F16) are the same sources and export the same C ABI;
+    pf_x3_element() tells them apart; one process can hold both (UNetModel(..., x3="f16"))."""
+    if not os.path.exists(_lib.lib_path("f16")):
+        from polyffusion_amd.build import build
+        build(verbose=False, variant="f16")
+    l16 = _lib.load("f16")
+    for name in _lib.SIGNATURES:
+        assert hasattr(l16, name), f"{name} not exported by libpfhip_f16.so"
+    assert l16.pf_x3_element() == 1 and _lib.load("").pf_x3_element() == 0
+    assert l16 is not _lib.load("") and l16 is _lib.load("f16")
+    assert l16.pf_version() == _lib.load("").pf_version()
+    # host-side packing differs (fp16 pieces of 256 w against bf16 pieces of w): same byte count, other bytes
+    import numpy as np
+    w = np.random.default_rng(0).standard_normal((64, 16)).astype(np.float32) * 0.05
+    outs = []
+    for L in (_lib.load(""), l16):
+        dst = np.zeros(2 * 64 * 16, dtype=np.uint16)
+        assert L.pf_pack_gemm_weight_bf16x3(w.ctypes.data, 64, 16, 1, dst.ctypes.data) == 0
+        outs.append(dst)
+    hi16 = outs[1].view(np.float16).reshape(2, 2, 64, 8)       # [K/8][plane][N][8]
+    rec = (hi16[:, 0].astype(np.float64) + hi16[:, 1].astype(np.float64)) / 256.0
+    assert np.abs(rec.transpose(1, 0, 2).reshape(64, 16) - w).max() < 2.0 ** -21 * 0.3       # 22 mantissa bits of |w| < 0.3
+    b = (outs[0].astype(np.uint32) << 16).view(np.float32).reshape(2, 2, 64, 8)
+    rec_b = b[:, 0].astype(np.float64) + b[:, 1]
+    assert np.abs(rec_b.transpose(1, 0, 2).reshape(64, 16) - w).max() < 2.0 ** -16 * 0.3
+
+
 def _unet(lib, cfg: UNetConfig, h=128, w=128):
     from polyffusion_amd.unet import UNetModel
     return UNetModel(in_channels=cfg.in_channels, out_channels=cfg.out_channels, channels=cfg.channels,

@@ -189,7 +189,7 @@ def test_qkv_planes_and_bf16x3_attention(lib, B, L, H, wide, monkeypatch):
     run_conv(lib, x0=xd, c0=c, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, w), n=3 * c, prologue=3,
              sc=dev(gamma), sh=dev(beta), mean=mu, rstd=rs, out=dummy, ld_out=3 * c, precision=1, qkv_planes=planes)
     # the planes reconstruct the projection: hi + lo == qkv to ~2^-17
-    pl = planes.view(torch.bfloat16).float().cpu().view(6, B, L * c)
+    pl = planes.view(_lib.x3_torch_dtype()).float().cpu().view(6, B, L * c)
     qrec = (pl[0] + pl[1]).view(B, L, c)
     assert (qrec - qkv[..., :c]).abs().max() < 3e-4
     out = torch.empty(B, L, c, device="cuda")
@@ -201,8 +201,8 @@ def test_qkv_planes_and_bf16x3_attention(lib, B, L, H, wide, monkeypatch):
 
 def _split_planes(x):
     """fp32 [M][K] -> the bf16 hi|lo plane pair a producer epilogue writes (as a float32-typed byte buffer)."""
-    hi = x.to(torch.bfloat16)
-    lo = (x - hi.float()).to(torch.bfloat16)
+    hi = x.to(_lib.x3_torch_dtype())
+    lo = (x - hi.float()).to(_lib.x3_torch_dtype())
     return torch.cat([hi.reshape(-1), lo.reshape(-1)]).cuda().view(torch.float32)
 
 
@@ -222,7 +222,7 @@ def test_planes_gemm_chain(lib, B, L, k, n):
     op = torch.zeros(B * L * n, device="cuda")
     run_conv(lib, x0=ap, c0=k, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, w), n=n, bias=dev(bias),
              res=dev(res), ld_res=n, out=op, ld_out=n, precision=1, a_planes=1, out_planes=op)
-    pl = op.view(torch.bfloat16).float().cpu().view(2, B, L, n)
+    pl = op.view(_lib.x3_torch_dtype()).float().cpu().view(2, B, L, n)
     assert (pl[0] + pl[1] - ref).abs().max().item() < TOL_OP
     # GeGLU projection from fp32 input -> planes, then consumed by a planes GEMM
     if n % 64 == 0:
@@ -235,7 +235,7 @@ def test_planes_gemm_chain(lib, B, L, k, n):
         gp = torch.zeros(B * L * n, device="cuda")
         run_conv(lib, x0=dev(x), c0=k, batch=B, hin=1, win=L, ks=1, stride=1, ups=0, w=pack3(lib, wi), n=2 * n,
                  bias=dev(bi), geglu=1, out=gp, ld_out=n, precision=1, out_planes=gp)
-        pl = gp.view(torch.bfloat16).float().cpu().view(2, B, L, n)
+        pl = gp.view(_lib.x3_torch_dtype()).float().cpu().view(2, B, L, n)
         assert (pl[0] + pl[1] - gref).abs().max().item() < TOL_OP
         w2 = rnd((k, n), 97, n ** -0.5)
         out2 = torch.empty(B, L, k, device="cuda")
@@ -262,7 +262,7 @@ def test_attention_planes_output(lib, L, wide, monkeypatch):
     op = torch.zeros(B * L * c, device="cuda")
     _lib.check(lib.pf_attention_bf16x3(planes.data_ptr(), None, c, op.data_ptr(), B, H, L, form, _lib.current_stream()))
     torch.cuda.synchronize()
-    pl = op.view(torch.bfloat16).float().cpu().view(2, B, L, c)
+    pl = op.view(_lib.x3_torch_dtype()).float().cpu().view(2, B, L, c)
     assert (pl[0] + pl[1] - ref).abs().max().item() < 3e-4
 
 
@@ -313,7 +313,7 @@ def test_ln_planes_feeds_the_projection(lib, B, L, H):
     gd, bd = dev(gamma), dev(beta)
     _lib.check(lib.pf_ln_planes(xd.data_ptr(), B * L, c, 1e-5, gd.data_ptr(), bd.data_ptr(), lnp.data_ptr(),
                                 _lib.current_stream()))
-    pl = lnp.view(torch.bfloat16).float().cpu().view(2, B, L, c)
+    pl = lnp.view(_lib.x3_torch_dtype()).float().cpu().view(2, B, L, c)
     assert (pl[0] + pl[1] - xn).abs().max().item() < 1e-4
     planes = torch.zeros(B * L * 3 * c, dtype=torch.float32, device="cuda")
     dummy = torch.empty(1, device="cuda")
@@ -514,7 +514,7 @@ def test_attention_key_split_form_small_batches(lib, B, L):
     assert d < 2e-5 and (need == 0) == (d == 0.0)          # merged partial sums: another summation order; no split: the same launch
     op = torch.zeros(B * L * c, device="cuda")
     _lib.check(lib.pf_attention_bf16x3_split(planes.data_ptr(), None, c, op.data_ptr(), B, H, L, scratch.data_ptr(), need, st))
-    pl = op.view(torch.bfloat16).float().view(2, B, L, c)
+    pl = op.view(_lib.x3_torch_dtype()).float().view(2, B, L, c)
     assert (pl[0] + pl[1] - out).abs().max().item() < 2e-5 * max(1.0, out.abs().max().item())
     for _ in range(4):
         o2 = torch.empty_like(out)

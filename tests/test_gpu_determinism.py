@@ -111,7 +111,7 @@ def test_attention_is_bit_reproducible(L, B, wide, monkeypatch):
     lib = _lib.load()
     H, c = 4, 256
     g = torch.Generator().manual_seed(L + B)
-    planes = (torch.randn(B * L * 3 * c * 2, generator=g) * 0.7).to(torch.bfloat16).cuda()
+    planes = (torch.randn(B * L * 3 * c * 2, generator=g) * 0.7).to(_lib.x3_torch_dtype()).cuda()
     st = _lib.current_stream()
     for as_planes in (False, True):
         outs = []

@@ -64,7 +64,7 @@ def test_fused_mlp_vs_torch_and_vs_the_unfused_chain(lib, B, L):
     _lib.check(lib.pf_mlp_geglu_fused(xd.data_ptr(), B, L, gd.data_ptr(), bd.data_ptr(), 1e-5, p1.data_ptr(), b1d.data_ptr(),
                                       p2.data_ptr(), b2d.data_ptr(), None, op.data_ptr(), st))
     torch.cuda.synchronize()
-    pl = op.view(torch.bfloat16).float().view(2, B, L, C)
+    pl = op.view(_lib.x3_torch_dtype()).float().view(2, B, L, C)
     assert (pl[0] + pl[1] - out).abs().max().item() < 2e-5 * max(1.0, out.abs().max().item())   # a plane pair carries 16 mantissa bits
     # bit-reproducible
     for _ in range(4):

@@ -25,13 +25,16 @@ def torchrun(args, port, timeout=600, nproc=2):
 
 def test_bench_two_ranks():
     out = torchrun(["bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--profile-steps", "0", "--fp32-steps", "2",
-                    "--small-batch-steps", "0"], 29641)
+                    "--f16x3-steps", "2", "--small-batch-steps", "0"], 29641)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # rank 0 prints the one JSON line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["devices_seen"] == [0, 0] and d["scaling"] == "weak"
     assert d["config"]["global_batch"] == 32 and d["value"] > 0 and "cpu_baseline" not in d and d["fp32_mode"]["steps_per_s"] > 0
+    # the fp16-split leg: a second model in libpfhip_f16.so on every rank (its weights broadcast like the first's), both splits' distance to f32
+    h = d["f16x3_mode"]
+    assert h["steps_per_s"] > 0 and h["eps_rel_diff_vs_f32_mode"]["f16x3"] < h["eps_rel_diff_vs_f32_mode"]["bf16x3"] < 1e-3
     # value = steps of all ranks / max-over-ranks time
     assert abs(d["value"] - 2 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) / d["value"] < 1e-3
     # every rank's own step time is in the line (a straggler on a real node shows as max >> min); the host-clock figure bounds them
@@ -43,7 +46,7 @@ def test_bench_eight_ranks_on_one_device():
     """The shape the driver's scaling run has - `--gpus 8`, one rank per GPU - with all eight ranks on device 0 over gloo: rank / offset
     bookkeeping for eight shards, the weight broadcast to seven receivers, barriers, max-over-ranks timing and the per-rank step times."""
     out = torchrun(["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1", "--windows", "2", "--profile-steps", "0", "--fp32-steps", "0",
-                    "--small-batch-steps", "0"], 29649, nproc=8, timeout=900)
+                    "--f16x3-steps", "0", "--small-batch-steps", "0"], 29649, nproc=8, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1

@@ -47,7 +47,7 @@ def _fused(lib, xd, B, L, sc, sh, stats, tiles, gg, gb, p_in, b_in, lg, lb, p_qk
 
 def _decode(planes, B, L):
     """6 bf16 planes -> [3][B*L*C] floats (hi + lo) in the buffer's own element order (Q, K row-major; V^T head-major, permuted)."""
-    pl = planes.view(torch.bfloat16).float().view(3, 2, B * L * C)
+    pl = planes.view(_lib.x3_torch_dtype()).float().view(3, 2, B * L * C)
     return pl[:, 0] + pl[:, 1]
 
 

@@ -5,7 +5,7 @@ names=$1; reps=${2:-3}
 mkdir -p gpurun_out/ab
 cp polyffusion_amd/libpfhip.so /tmp/cur.so
 for n in $names; do [ $n = cur ] || cp build/exp/libpfhip_$n.so /tmp/$n.so; done
-F="--steps 50 --warmup 5 --no-cpu-baseline --profile-steps 0 --small-batch-steps 0 --fp32-steps 0"
+F="--steps 50 --warmup 5 --no-cpu-baseline --profile-steps 0 --small-batch-steps 0 --fp32-steps 0 --f16x3-steps 0"
 : > gpurun_out/ab/ab_libs.txt
 for rep in $(seq $reps); do
   for n in $names; do

@@ -2,7 +2,7 @@
 # same-box A/B of one plan option on the small-batch legs: bash tools/ab_option_small.sh mlp_fused [reps]   (auto vs forced on)
 opt=$1; reps=${2:-2}
 mkdir -p gpurun_out/ab
-F="--steps 20 --warmup 5 --windows 1 --no-cpu-baseline --profile-steps 0 --fp32-steps 0 --no-pmc --small-batch-steps 40"
+F="--steps 20 --warmup 5 --windows 1 --no-cpu-baseline --profile-steps 0 --fp32-steps 0 --f16x3-steps 0 --no-pmc --small-batch-steps 40"
 : > gpurun_out/ab/ab_small_$opt.txt
 for rep in $(seq $reps); do
   for v in auto 0 1; do

@@ -3,7 +3,7 @@
 reps=${1:-3}
 mkdir -p gpurun_out/ab
 cp polyffusion_amd/libpfhip.so /tmp/cur.so
-F="--steps 50 --warmup 5 --no-cpu-baseline --profile-steps 0 --small-batch-steps 0 --fp32-steps 0 --no-pmc"
+F="--steps 50 --warmup 5 --no-cpu-baseline --profile-steps 0 --small-batch-steps 0 --fp32-steps 0 --f16x3-steps 0 --no-pmc"
 : > gpurun_out/ab/ab_prev.txt
 for rep in $(seq $reps); do
   for n in prev cur; do

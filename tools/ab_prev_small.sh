@@ -4,7 +4,7 @@
 reps=${1:-3}
 mkdir -p gpurun_out/ab
 cp polyffusion_amd/libpfhip.so /tmp/cur.so
-F="--steps 30 --warmup 5 --windows 3 --no-cpu-baseline --profile-steps 0 --fp32-steps 0 --no-pmc --small-batch-steps 40 --no-long-parity"
+F="--steps 30 --warmup 5 --windows 3 --no-cpu-baseline --profile-steps 0 --fp32-steps 0 --f16x3-steps 0 --no-pmc --small-batch-steps 40 --no-long-parity"
 : > gpurun_out/ab/ab_prev_small.txt
 for rep in $(seq $reps); do
   for n in prev cur; do

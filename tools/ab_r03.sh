@@ -3,7 +3,7 @@
 # usage: bash tools/ab_r03.sh [reps] [extra bench flags]   -> gpurun_out/ab/ab_r03.txt
 reps=${1:-3}; shift
 mkdir -p gpurun_out/ab
-F="--steps 50 --warmup 5 --no-cpu-baseline --profile-steps 0 --small-batch-steps 0 --fp32-steps 0"
+F="--steps 50 --warmup 5 --no-cpu-baseline --profile-steps 0 --small-batch-steps 0 --fp32-steps 0 --f16x3-steps 0"
 : > gpurun_out/ab/ab_r03.txt
 for rep in $(seq $reps); do
   (cd build/r03 && python bench.py $F "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('r03  value', d['value'], 'ms', d['ms_per_step'])") | tee -a gpurun_out/ab/ab_r03.txt

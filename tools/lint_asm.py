@@ -15,7 +15,7 @@ every instruction OUTSIDE inline asm that reads or writes a register a hidden lo
 are not modelled: they share lgkmcnt, so a pending one only makes a hand-counted `lgkmcnt(N)` stricter (LDS accesses outstanding
 <= all outstanding <= N), never weaker.
 
-usage: python tools/lint_asm.py [file.s ...]      (no arguments: compiles the three sources to build/asm/ and checks them)
+usage: python tools/lint_asm.py [--variant=f16] [file.s ...]   (no files: compiles the sources to build/asm[_variant]/ and checks them)
 exit status 1 when a violation is found.
 """
 from __future__ import annotations
@@ -29,7 +29,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SOURCES = ["conv_bf16x3.hip", "gemm_planes_bf3.hip", "attention_bf3.hip", "mlp_fused_bf3.hip", "preattn_fused_bf3.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 sys.path.insert(0, REPO)
-from polyffusion_amd.build import EXTRA_FLAGS  # noqa: E402  (the lint must read the assembly the library is built from)
+from polyffusion_amd.build import EXTRA_FLAGS, VARIANTS  # noqa: E402  (the lint must read the assembly the library is built from)
 
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 
@@ -163,15 +163,15 @@ def lint_file(path: str) -> int:
     return n_bad
 
 
-def compile_to_asm() -> list:
-    out_dir = os.path.join(REPO, "build", "asm")
+def compile_to_asm(variant: str = "") -> list:
+    out_dir = os.path.join(REPO, "build", "asm" + ("_" + variant if variant else ""))
     os.makedirs(out_dir, exist_ok=True)
     procs, outs = [], []
     for src in SOURCES:
         out = os.path.join(out_dir, src.replace(".hip", ".s"))
         outs.append(out)
         procs.append(subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                                       "-Wno-unused-command-line-argument"] + EXTRA_FLAGS.get(src, []) +
+                                       "-Wno-unused-command-line-argument"] + EXTRA_FLAGS.get(src, []) + VARIANTS[variant] +
                                       [os.path.join(REPO, "polyffusion_amd", "csrc", src), "-o", out]))
     for p in procs:
         if p.wait() != 0:
@@ -180,7 +180,9 @@ def compile_to_asm() -> list:
 
 
 def main(argv) -> int:
-    files = argv or compile_to_asm()
+    variants = [a.split("=", 1)[1] for a in argv if a.startswith("--variant=")]
+    argv = [a for a in argv if not a.startswith("--variant=")]
+    files = argv or [f for v in (variants or [""]) for f in compile_to_asm(v)]
     total = sum(lint_file(f) for f in files)
     print("lint_asm:", "clean" if total == 0 else f"{total} violation(s)")
     return 1 if total else 0

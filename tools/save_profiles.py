@@ -12,7 +12,7 @@ for line in open(os.path.join(src, "trace.log"), errors="replace"):
     m = re.search(r'"value": ([0-9.]+), "unit": "steps/s"', line)
     if m:
         rate = m.group(1)
-B = "python bench.py --profile-steps 0 --no-cpu-baseline --small-batch-steps 0 --fp32-steps 0 --windows 1"
+B = "python bench.py --profile-steps 0 --no-cpu-baseline --small-batch-steps 0 --fp32-steps 0 --f16x3-steps 0 --windows 1"
 kt = open(os.path.join(src, "kernel_trace.md")).read()
 gaps = open(os.path.join(src, "gaps.txt")).read().strip().splitlines()[-2:]
 with open(f"profiles/{tag}_kernel_trace_bench_b16_bf16x3.md", "w") as f:
