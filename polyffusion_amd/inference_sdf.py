@@ -673,6 +673,12 @@ def main(argv=None):
     say(f"generating {S} song(s) x {B} segment(s) with uncond_scale = {args.uncond_scale} on {world} GPU(s)")
     gen, expmt = generate_songs(model, params, args, cond, cond_mid, orig, mask, seed, rank, world, cond_concat=cond_concat)
     gen = pfdist.gather_rows(gen, S, rank, world)   # [S, ...] on every rank (131 KB per image; the only end-of-run exchange)
+    if not bool(torch.isfinite(gen).all()):
+        # the note threshold (> 0.5) would turn a NaN into silence: refuse instead.  The one known way to get here is an activation beyond
+        # fp16's range in the f16x3 mode on a checkpoint the probe inputs did not exercise (include/pfhip.h pf_x3_element)
+        mode = model.ldm.eps_model.precision
+        raise SystemExit(f"non-finite values in the generated piano rolls (precision {mode})"
+                         + ("; f16x3 overflows beyond 65504: rerun with --precision bf16x3 or f32" if mode == "f16x3" else ""))
     if rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)
         for i in range(S):

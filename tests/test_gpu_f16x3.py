@@ -217,3 +217,27 @@ def test_cli_precision_auto_tries_f16x3_before_falling_back_to_f32(tmp_path, mon
     a_auto3, log = go("auto3")
     assert "precision: f32 (f16x3 vs f32" in log
     assert np.array_equal(a_auto3, a_32)
+
+
+@needs_default_bf16
+def test_cli_refuses_non_finite_results(tmp_path):
+    """An explicit --precision f16x3 on a checkpoint whose residual stream leaves fp16's range: the run stops with a message instead of
+    writing silence (the note threshold would read NaN as 'no note'); bf16x3 on the same checkpoint runs."""
+    import yaml
+    from polyffusion_amd import inference_sdf
+    from ckpt_fixture import full_state, write_legacy_pt
+    from test_gpu_checkpoint_cli import PARAMS, states
+    us, cs = states()
+    key = next(k for k in us if k.endswith("proj_in.weight"))
+    us[key] = (us[key] * np.float32(100)).astype(np.float32)
+    us[key.replace("proj_in.weight", "norm.weight")] = (us[key.replace("proj_in.weight", "norm.weight")] * np.float32(2000)).astype(np.float32)
+    run = tmp_path / "run"
+    (run / "chkpts").mkdir(parents=True)
+    (run / "params.yaml").write_text(yaml.safe_dump(dict(PARAMS, batch_size=16, learning_rate=5e-5)))
+    write_legacy_pt(str(run / "chkpts" / "weights_best.pt"), full_state(us, cs))
+    base = ["--chkpt_path", str(run / "chkpts" / "weights_best.pt"), "--synthetic", "--length", "2", "--ddim", "--ddim_steps", "4",
+            "--uncond_scale", "1.0", "--seed", "5", "--num_generate", "1"]
+    assert inference_sdf.main(base + ["--output_dir", str(tmp_path / "b"), "--precision", "bf16x3"]) == 0
+    with pytest.raises(SystemExit, match="non-finite.*f16x3 overflows"):
+        inference_sdf.main(base + ["--output_dir", str(tmp_path / "h"), "--precision", "f16x3"])
+    assert not os.path.exists(tmp_path / "h") or not os.listdir(tmp_path / "h")
