@@ -25,11 +25,11 @@ __device__ unsigned long long g_trace_attn[4096];
 #define TRA() do {} while (0)
 #endif
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef x3_t x3x4 __attribute__((ext_vector_type(4)));
 
 struct AttnP3 {
-  const __bf16* planes;   // [qh | ql | kh | kl | vth | vtl], each B*L*C elements
-  float* o; int ldo; __bf16* o_planes;
+  const x3_t* planes;   // [qh | ql | kh | kl | vth | vtl], each B*L*C elements
+  float* o; int ldo; x3_t* o_planes;
   int B, H, L;
   float scale;
   FastDiv d_nqt, d_h;     // reciprocals of the query tiles per (batch, head) and of H (tile decode without emulated divisions)
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
   constexpr int DH = 64, KT = 64, NT = NWAVES * 64, NP = 2048 / NT;   // NP direct-to-LDS pieces per thread and tile
   constexpr int STAGE = 4 * KT * DH;          // bf16 elements per stage: K hi, K lo, V^T hi, V^T lo (8 KB each)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);   // [RING stages][4 arrays][64 rows][64]
+  x3_t* sm = reinterpret_cast<x3_t*>(smem_raw);   // [RING stages][4 arrays][64 rows][64]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA destinations (M0) stay in SGPRs
@@ -75,20 +75,20 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
   const int qi = qt * (NWAVES * 32) + wave * 32 + (lane & 31);
 
   // Q fragments (B operand of S^T): lane (q, g) holds d = 16 s + 8 g .. +7 of its query, hi and lo
-  bf16x8 qh[4], ql[4];
+  x3x8 qh[4], ql[4];
   {
-    const __bf16* qp = p.planes + ((size_t)b * L + qi) * C + h * DH + 8 * g;
+    const x3_t* qp = p.planes + ((size_t)b * L + qi) * C + h * DH + 8 * g;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      qh[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-      ql[s] = *reinterpret_cast<const bf16x8*>(qp + MC + 16 * s);
+      qh[s] = *reinterpret_cast<const x3x8*>(qp + 16 * s);
+      ql[s] = *reinterpret_cast<const x3x8*>(qp + MC + 16 * s);
     }
   }
 
   // direct-to-LDS tile loads: 2048 16-byte units per stage, NP per thread; unit u = tid + j*NT -> array u/512 (K hi, K lo,
   // V^T hi, V^T lo), row (u%512)/8, slot u%8
-  const __bf16* kbase = p.planes + 2 * MC + (size_t)b * L * C + h * DH;           // + plane*MC + key*C + d
-  const __bf16* vbase = p.planes + 4 * MC + ((size_t)b * p.H + h) * DH * L;       // + plane*MC + d*L + key
+  const x3_t* kbase = p.planes + 2 * MC + (size_t)b * L * C + h * DH;           // + plane*MC + key*C + d
+  const x3_t* vbase = p.planes + 4 * MC + ((size_t)b * p.H + h) * DH * L;       // + plane*MC + d*L + key
   // (buffer-form direct-to-LDS loads, dma16 of conv_common.h; the lo plane lies MC elements behind the hi plane: with 2 * MC bytes >= 2 GiB
   // the launcher refuses, so every offset fits the 32-bit offset registers)
   const __amdgpu_buffer_rsrc_t rsK = dma_resource(kbase), rsV = dma_resource(vbase);
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
     const int u = tid + j * NT;
     const int arr = u >> 9, row = (u & 511) >> 3;
     const int src_slot = (u & 7) ^ ((row >> 1) & 7);     // swizzle on the SOURCE side; the LDS image stays lane-linear
-    __bf16* lp = sm + stage * STAGE + (j * NT + wave * 64) * 8;   // wave-uniform; the hardware adds lane*16 B
+    x3_t* lp = sm + stage * STAGE + (j * NT + wave * 64) * 8;   // wave-uniform; the hardware adds lane*16 B
     if (arr < 2) dma16(rsK, (int)(((size_t)(arr & 1) * MC + (size_t)row * C + src_slot * 8) * 2), t * KT * C * 2, lp);
     else dma16(rsV, (int)(((size_t)(arr & 1) * MC + (size_t)row * L + src_slot * 8) * 2), t * KT * 2, lp);
   };
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
   // sixteen consecutive 128-byte rows must spread over both halves of the 256 bytes AND all eight slots of each half - with (row & 7)
   // rows r and r + 8 met in the same banks (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE; tools/micro/lds_b128.hip: 32 against
   // 24.8 cycles per wave-instruction with four waves reading).
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) __bf16*)sm;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) x3_t*)sm;
   unsigned faddr[4];
 #pragma unroll
   for (int sp = 0; sp < 4; ++sp) faddr[sp] = lds0 + r31 * 128 + (((2 * sp + g) ^ ((r31 >> 1) & 7)) * 16);
@@ -135,12 +135,12 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
   // interleaved with the MFMAs of the current one.  LDS waits are counted by hand (inline-asm reads, conv_common.h).
   // One barrier per tile: it publishes tile t and frees the other stage for tile t+1.
   typedef float f32x8 __attribute__((ext_vector_type(8)));
-  auto psplit = [&](const f32x16& sv, int half, bf16x8& ph, bf16x8& pl) {   // whole-vector conversions (packed cvt path)
+  auto psplit = [&](const f32x16& sv, int half, x3x8& ph, x3x8& pl) {   // whole-vector conversions (packed cvt path)
     f32x8 v;
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = sv[half * 8 + q];
-    ph = __builtin_convertvector(v, bf16x8);
-    pl = __builtin_convertvector(v - __builtin_convertvector(ph, f32x8), bf16x8);
+    ph = __builtin_convertvector(v, x3x8);
+    pl = __builtin_convertvector(v - __builtin_convertvector(ph, f32x8), x3x8);
   };
   auto tile_body = [&](auto stc, int t) {
     constexpr int ST = decltype(stc)::value;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
     for (int kf = 0; kf < 2; ++kf)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kf][r] = 0.f;
-    bf16x8 fh[2][2], fl[2][2];   // [buffer][fragment]
+    x3x8 fh[2][2], fl[2][2];   // [buffer][fragment]
     fh[0][0] = lds_read128<SB0>(faddr[0]);          fl[0][0] = lds_read128<SB0 + ARR_B>(faddr[0]);
     fh[0][1] = lds_read128<SB0 + 4096>(faddr[0]);   fl[0][1] = lds_read128<SB0 + ARR_B + 4096>(faddr[0]);
     static_for<0, 4>([&](auto ic) {
@@ -178,12 +178,12 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
       if constexpr (NP == 8) { issue_piece(tn, STN, 2 * sp); issue_piece(tn, STN, 2 * sp + 1); }
       else issue_piece(tn, STN, sp);
       lgkm_wait<4>(); SB();
-      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b][0], qh[sp], s[0], 0, 0, 0);
-      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b][1], qh[sp], s[1], 0, 0, 0);
-      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][0], ql[sp], s[0], 0, 0, 0);
-      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][1], ql[sp], s[1], 0, 0, 0);
-      s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][0], qh[sp], s[0], 0, 0, 0);
-      s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][1], qh[sp], s[1], 0, 0, 0);
+      s[0] = x3_mfma_32x32x16(fl[b][0], qh[sp], s[0], 0, 0, 0);
+      s[1] = x3_mfma_32x32x16(fl[b][1], qh[sp], s[1], 0, 0, 0);
+      s[0] = x3_mfma_32x32x16(fh[b][0], ql[sp], s[0], 0, 0, 0);
+      s[1] = x3_mfma_32x32x16(fh[b][1], ql[sp], s[1], 0, 0, 0);
+      s[0] = x3_mfma_32x32x16(fh[b][0], qh[sp], s[0], 0, 0, 0);
+      s[1] = x3_mfma_32x32x16(fh[b][1], qh[sp], s[1], 0, 0, 0);
       SB();
     });
     TRA();
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
     TRA();
     // ---- O^T += V^T . P^T : key block kb (16 keys); registers 8kb'..8kb'+7 of a score fragment are this lane's 8 keys of
     // block kb.  Block 0's V^T fragments sit in buffer 0 (loaded by S step 3: b ^ 1 == 0). ----
-    bf16x8 ph[2], pl[2];
+    x3x8 ph[2], pl[2];
     psplit(s[0], 0, ph[0], pl[0]);
     static_for<0, 4>([&](auto jc) {
       constexpr int kb = decltype(jc)::value, b = kb & 1;
@@ -228,13 +228,13 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
         fh[b ^ 1][1] = lds_read128<SB0 + 2 * ARR_B + 4096>(faddr[kb + 1]);   fl[b ^ 1][1] = lds_read128<SB0 + 3 * ARR_B + 4096>(faddr[kb + 1]);
       }
       lgkm_wait<(kb < 3) ? 4 : 0>(); SB();
-      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b][0], ph[b], oacc[0], 0, 0, 0);
-      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[b][1], ph[b], oacc[1], 0, 0, 0);
+      oacc[0] = x3_mfma_32x32x16(fl[b][0], ph[b], oacc[0], 0, 0, 0);
+      oacc[1] = x3_mfma_32x32x16(fl[b][1], ph[b], oacc[1], 0, 0, 0);
       if constexpr (kb < 3) psplit(s[(kb + 1) >> 1], (kb + 1) & 1, ph[b ^ 1], pl[b ^ 1]);   // next block's split, in the MFMA shadow
-      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][0], pl[b], oacc[0], 0, 0, 0);
-      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][1], pl[b], oacc[1], 0, 0, 0);
-      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][0], ph[b], oacc[0], 0, 0, 0);
-      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[b][1], ph[b], oacc[1], 0, 0, 0);
+      oacc[0] = x3_mfma_32x32x16(fh[b][0], pl[b], oacc[0], 0, 0, 0);
+      oacc[1] = x3_mfma_32x32x16(fh[b][1], pl[b], oacc[1], 0, 0, 0);
+      oacc[0] = x3_mfma_32x32x16(fh[b][0], ph[b], oacc[0], 0, 0, 0);
+      oacc[1] = x3_mfma_32x32x16(fh[b][1], ph[b], oacc[1], 0, 0, 0);
       SB();
     });
   };
@@ -268,12 +268,12 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 4 ? 2 : 1) void attn_bf3_ker
       v[0] = oacc[df][4 * c + 0] * inv; v[1] = oacc[df][4 * c + 1] * inv;
       v[2] = oacc[df][4 * c + 2] * inv; v[3] = oacc[df][4 * c + 3] * inv;
       if (p.o_planes) {   // hi/lo planes [M][C] for the to_out planes GEMM
-        bf16x4 h4 = __builtin_convertvector(v, bf16x4);
+        x3x4 h4 = __builtin_convertvector(v, x3x4);
         const f32x4 hf = __builtin_convertvector(h4, f32x4);
-        bf16x4 l4 = __builtin_convertvector(v - hf, bf16x4);
-        __bf16* pp = p.o_planes + ((size_t)b * L + qi) * C + h * DH + df * 32 + 8 * c + 4 * g;
-        *reinterpret_cast<bf16x4*>(pp) = h4;
-        *reinterpret_cast<bf16x4*>(pp + MC) = l4;
+        x3x4 l4 = __builtin_convertvector(v - hf, x3x4);
+        x3_t* pp = p.o_planes + ((size_t)b * L + qi) * C + h * DH + df * 32 + 8 * c + 4 * g;
+        *reinterpret_cast<x3x4*>(pp) = h4;
+        *reinterpret_cast<x3x4*>(pp + MC) = l4;
       } else {
         *reinterpret_cast<f32x4*>(op + df * 32 + 8 * c + 4 * g) = v;
       }
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
   constexpr int NWAVES = 4, QF = 2, DH = 64, KT = 64, NT = NWAVES * 64, NP = 2048 / NT;
   constexpr int STAGE = 4 * KT * DH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);   // [RING stages][K hi, K lo, V^T hi, V^T lo][64 rows][64]
+  x3_t* sm = reinterpret_cast<x3_t*>(smem_raw);   // [RING stages][K hi, K lo, V^T hi, V^T lo][64 rows][64]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -320,19 +320,19 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
   const size_t MC = (size_t)p.B * L * C;
   const int qi = qt * (NWAVES * 32 * QF) + wave * (32 * QF) + (lane & 31);   // + 32 qf
 
-  bf16x8 qh[QF][4], ql[QF][4];
+  x3x8 qh[QF][4], ql[QF][4];
 #pragma unroll
   for (int qf = 0; qf < QF; ++qf) {
-    const __bf16* qp = p.planes + ((size_t)b * L + qi + 32 * qf) * C + h * DH + 8 * g;
+    const x3_t* qp = p.planes + ((size_t)b * L + qi + 32 * qf) * C + h * DH + 8 * g;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      qh[qf][s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
-      ql[qf][s] = *reinterpret_cast<const bf16x8*>(qp + MC + 16 * s);
+      qh[qf][s] = *reinterpret_cast<const x3x8*>(qp + 16 * s);
+      ql[qf][s] = *reinterpret_cast<const x3x8*>(qp + MC + 16 * s);
     }
   }
 
-  const __bf16* kbase = p.planes + 2 * MC + (size_t)b * L * C + h * DH;
-  const __bf16* vbase = p.planes + 4 * MC + ((size_t)b * p.H + h) * DH * L;
+  const x3_t* kbase = p.planes + 2 * MC + (size_t)b * L * C + h * DH;
+  const x3_t* vbase = p.planes + 4 * MC + ((size_t)b * p.H + h) * DH * L;
   // piece j of a tile (unit u = tid + 256 j): array j/2 (K hi, K lo, V^T hi, V^T lo), row tid/8 + 32 (j & 1), 16-byte slot
   // (tid & 7) ^ ((row >> 1) & 7) - the same slot for every j.  The source address is a wave-uniform base (tile, array, row half: scalar ALU)
   // plus one 32-bit per-thread offset per operand, so an issue costs no vector instructions and no address registers.
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
   const __amdgpu_buffer_rsrc_t rsK = dma_resource(kbase), rsV = dma_resource(vbase);
   auto issue_piece = [&](int t, int stage, int j) {
     const int arr = j >> 1, half = j & 1;
-    __bf16* lp = sm + stage * STAGE + (j * NT + wave * 64) * 8;
+    x3_t* lp = sm + stage * STAGE + (j * NT + wave * 64) * 8;
     if (arr < 2) dma16(rsK, (int)koff, (int)(((size_t)(arr & 1) * MC + (size_t)(t * KT + 32 * half) * C) * 2), lp);
     else dma16(rsV, (int)voff, (int)(((size_t)(arr & 1) * MC + (size_t)(32 * half) * L + t * KT) * 2), lp);
   };
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
 
   const int ntile = L / KT;
   const int r31 = lane & 31;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) __bf16*)sm;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) x3_t*)sm;
   unsigned faddr[4];
 #pragma unroll
   for (int sp = 0; sp < 4; ++sp) faddr[sp] = lds0 + r31 * 128 + (((2 * sp + g) ^ ((r31 >> 1) & 7)) * 16);
@@ -378,8 +378,8 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
 #define IC(N) std::integral_constant<int, (N)>{}
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  bf16x8 fh[2][2], fl[2][2];      // [buffer][fragment]
+  typedef x3_t x3x2 __attribute__((ext_vector_type(2)));
+  x3x8 fh[2][2], fl[2][2];      // [buffer][fragment]
   u32x4 phw[2][QF], plw[2][QF];   // probabilities of one key block as packed bf16 pairs, hi and lo [buffer][query fragment]
   float th0[8], th1[8];           // hi/lo split in flight (one slot per item of a key block)
 
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
     const float v0 = pv[qf][BLK >> 1][e], v1 = pv[qf][BLK >> 1][e + 1];
     if constexpr (ST == 0) {
       const f32x2 v = {v0, v1};
-      phw[BUF][qf][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // hi = RNE bf16 pair (key 2j in the low half)
+      phw[BUF][qf][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, x3x2));   // hi = RNE bf16 pair (key 2j in the low half)
     } else if constexpr (ST == 1) {   // the float values of hi, rebuilt from the packed word
 #ifdef PF_X3_F16
       // (spelled as instructions: hipcc 7.2 folds `(float)bit_cast<half2>(phw[..][j])[i]` to element j = 0's conversion for every j)
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
       th1[j8] = v1 - th1[j8];
     } else {
       const f32x2 r = {th0[j8], th1[j8]};
-      plw[BUF][qf][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+      plw[BUF][qf][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, x3x2));
     }
   };
   auto copy_pair = [&](auto cc) __attribute__((always_inline)) {
@@ -516,19 +516,19 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
       // ---- the MFMA ----
       if constexpr (S_REG && DO_S) {
         constexpr int sp = R;
-        const bf16x8 a = prod == 0 ? fl[bb][kf] : fh[bb][kf];
-        const bf16x8 bq = prod == 1 ? ql[qf][sp] : qh[qf][sp];
+        const x3x8 a = prod == 0 ? fl[bb][kf] : fh[bb][kf];
+        const x3x8 bq = prod == 1 ? ql[qf][sp] : qh[qf][sp];
         if constexpr (sp == 0 && prod == 0) {
           const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          sacc[qf][kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, z, 0, 0, 0);
+          sacc[qf][kf] = x3_mfma_32x32x16(a, bq, z, 0, 0, 0);
         } else {
-          sacc[qf][kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, sacc[qf][kf], 0, 0, 0);
+          sacc[qf][kf] = x3_mfma_32x32x16(a, bq, sacc[qf][kf], 0, 0, 0);
         }
       }
       if constexpr (!S_REG && DO_PV) {
-        const bf16x8 a = prod == 0 ? fl[bb][kf] : fh[bb][kf];   // kf = V^T channel fragment here
-        const bf16x8 bp = __builtin_bit_cast(bf16x8, prod == 1 ? plw[bb][qf] : phw[bb][qf]);
-        oacc[qf][kf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bp, oacc[qf][kf], 0, 0, 0);
+        const x3x8 a = prod == 0 ? fl[bb][kf] : fh[bb][kf];   // kf = V^T channel fragment here
+        const x3x8 bp = __builtin_bit_cast(x3x8, prod == 1 ? plw[bb][qf] : phw[bb][qf]);
+        oacc[qf][kf] = x3_mfma_32x32x16(a, bp, oacc[qf][kf], 0, 0, 0);
       }
       // ---- one fragment read for the next region (gaps 4..7), into the buffer the previous region used ----
       if constexpr (m >= 4 && m < 8) {
@@ -536,12 +536,12 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
         constexpr int FO = (f >> 1) * 4096, PL = f & 1;
         if constexpr (NR < 4) {   // K step NR of tile t+1
           if constexpr (DO_S) {
-            const bf16x8 v = lds_read128<SB1 + PL * ARR_B + FO>(faddr[NR]);
+            const x3x8 v = lds_read128<SB1 + PL * ARR_B + FO>(faddr[NR]);
             if constexpr (PL == 0) fh[bb ^ 1][f >> 1] = v; else fl[bb ^ 1][f >> 1] = v;
           }
         } else if constexpr (NR < 8) {   // V^T key block NR - 4 of tile t
           if constexpr (DO_PV) {
-            const bf16x8 v = lds_read128<SB0 + (2 + PL) * ARR_B + FO>(faddr[NR - 4]);
+            const x3x8 v = lds_read128<SB0 + (2 + PL) * ARR_B + FO>(faddr[NR - 4]);
             if constexpr (PL == 0) fh[bb ^ 1][f >> 1] = v; else fl[bb ^ 1][f >> 1] = v;
           }
         }
@@ -598,12 +598,12 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
         v[0] = oacc[qf][df][4 * c + 0] * inv; v[1] = oacc[qf][df][4 * c + 1] * inv;
         v[2] = oacc[qf][df][4 * c + 2] * inv; v[3] = oacc[qf][df][4 * c + 3] * inv;
         if (p.o_planes) {
-          bf16x4 h4 = __builtin_convertvector(v, bf16x4);
+          x3x4 h4 = __builtin_convertvector(v, x3x4);
           const f32x4 hf = __builtin_convertvector(h4, f32x4);
-          bf16x4 l4 = __builtin_convertvector(v - hf, bf16x4);
-          __bf16* pp = p.o_planes + ((size_t)b * L + qq) * C + h * DH + df * 32 + 8 * c + 4 * g;
-          *reinterpret_cast<bf16x4*>(pp) = h4;
-          *reinterpret_cast<bf16x4*>(pp + MC) = l4;
+          x3x4 l4 = __builtin_convertvector(v - hf, x3x4);
+          x3_t* pp = p.o_planes + ((size_t)b * L + qq) * C + h * DH + df * 32 + 8 * c + 4 * g;
+          *reinterpret_cast<x3x4*>(pp) = h4;
+          *reinterpret_cast<x3x4*>(pp + MC) = l4;
         } else {
           *reinterpret_cast<f32x4*>(op + df * 32 + 8 * c + 4 * g) = v;
         }
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256, 1) void attn_bf3_wide_kernel(AttnP3 p) {
 // Combine the key slices of the split form: out[q] = sum_s 2^(m_s - m) O_s[q] / sum_s 2^(m_s - m) l_s with m = max_s m_s (the online-softmax
 // merge, in the exp2 domain the kernel works in).  One thread per (query, four channels); fp32 rows or hi/lo planes like the kernel's own store.
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, int nsplit, int B, int H, int L,
-                                                        float* __restrict__ o, int ldo, __bf16* __restrict__ o_planes) {
+                                                        float* __restrict__ o, int ldo, x3_t* __restrict__ o_planes) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;     // over B*H*L*16
   const size_t nrow = (size_t)B * H * L;
   if (i >= nrow * 16) return;
@@ -632,11 +632,11 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
   const int C = H * 64;
   if (o_planes) {
     const size_t MC = (size_t)B * L * C;
-    const bf16x4 h4 = __builtin_convertvector(v, bf16x4);
-    const bf16x4 l4 = __builtin_convertvector(v - __builtin_convertvector(h4, f32x4), bf16x4);
-    __bf16* pp = o_planes + (b * L + q) * C + h * 64 + c4;
-    *reinterpret_cast<bf16x4*>(pp) = h4;
-    *reinterpret_cast<bf16x4*>(pp + MC) = l4;
+    const x3x4 h4 = __builtin_convertvector(v, x3x4);
+    const x3x4 l4 = __builtin_convertvector(v - __builtin_convertvector(h4, f32x4), x3x4);
+    x3_t* pp = o_planes + (b * L + q) * C + h * 64 + c4;
+    *reinterpret_cast<x3x4*>(pp) = h4;
+    *reinterpret_cast<x3x4*>(pp + MC) = l4;
   } else {
     *reinterpret_cast<f32x4*>(o + (b * L + q) * ldo + h * 64 + c4) = v;
   }
@@ -658,7 +658,7 @@ int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, 
   PF_REQUIRE((size_t)batch * l * n_heads * 64 * 2 * 2 < ((size_t)1 << 31), "attention_bf3: a plane pair must stay below 2 GiB (32-bit offsets of the direct-to-LDS loads)");
   // auto: the 256-query form where it still gives three quarters of the CUs a workgroup
   const bool wide = l % 256 == 0 && (form == PF_OPT_AUTO ? (l / 256) * n_heads * batch >= num_cus() * 3 / 4 : form == 1);
-  AttnP3 p{static_cast<const __bf16*>(planes), o, ldo, static_cast<__bf16*>(o_planes), batch, n_heads, l, 0.125f,
+  AttnP3 p{static_cast<const x3_t*>(planes), o, ldo, static_cast<x3_t*>(o_planes), batch, n_heads, l, 0.125f,
            make_fastdiv(wide ? l / 256 : l / 128), make_fastdiv(n_heads), 1, nullptr, nullptr, make_fastdiv(1)};
   int ns = 1;
   const size_t want = wide ? 0 : attention_bf3_split_floats(batch, n_heads, l, &ns);
@@ -677,7 +677,7 @@ int launch_attention_bf3(const void* planes, float* o, int ldo, void* o_planes, 
     PF_CHECK_HIP(hipGetLastError());
     const size_t n16 = (size_t)batch * n_heads * l * 16;
     hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, stream, p.part_o, p.part_ml, ns, batch, n_heads, l, o, ldo,
-                       static_cast<__bf16*>(o_planes));
+                       static_cast<x3_t*>(o_planes));
   } else hipLaunchKernelGGL((attn_bf3_kernel<4, 2>), dim3((l / 128) * n_heads * batch), dim3(256), 2 * 32768, stream, p);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;

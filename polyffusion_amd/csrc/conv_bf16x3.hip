@@ -36,7 +36,7 @@ __device__ unsigned long long g_trace[8192];
 #define TR() do {} while (0)
 #endif
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef x3_t x3x4 __attribute__((ext_vector_type(4)));
 
 // bf16 elements between two halo rows of one plane.  A pixel is 40 elements (80 B: consecutive pixels of a row are
 // conflict-free for ds_read_b128); a fragment's 32 pixels span TWO tile rows, and with the natural row pitch TWIN*40 the second
@@ -109,9 +109,9 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x / NT);   // wave group (K half), wave-uniform
   unsigned char* smem_raw = smem_all + kg * conv_bf3_group_lds<KS, STRIDE, TH, TW, BN, SKIP, KG>();
-  __bf16* sAh = reinterpret_cast<__bf16*>(smem_raw);
-  __bf16* sAl = sAh + APLANE;
-  __bf16* sW = sAl + APLANE;               // [WRING bufs][4 k8][2 planes][BN][8]
+  x3_t* sAh = reinterpret_cast<x3_t*>(smem_raw);
+  x3_t* sAl = sAh + APLANE;
+  x3_t* sW = sAl + APLANE;               // [WRING bufs][4 k8][2 planes][BN][8]
 
   const int tid = KG == 1 ? threadIdx.x : threadIdx.x % NT, lane = tid & 63;   // group-local
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA destinations (M0) and tile roles stay in SGPRs
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   };
   // staged halo values after the prologue transform, split into bf16 hi / lo quads (kept in registers between the
   // transform, which is scheduled in the shadow of a mid-chunk tap's MFMAs, and the LDS write at the chunk boundary)
-  bf16x4 qh[NA], ql[NA];
+  x3x4 qh[NA], ql[NA];
   auto transformPiece = [&](int i) {
     {
       f32x4 v = ra[i];
@@ -221,9 +221,9 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
           if (PRO == 1) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
         }
       }
-      qh[i] = __builtin_convertvector(v, bf16x4);
+      qh[i] = __builtin_convertvector(v, x3x4);
       const f32x4 hf = __builtin_convertvector(qh[i], f32x4);
-      ql[i] = __builtin_convertvector(v - hf, bf16x4);
+      ql[i] = __builtin_convertvector(v - hf, x3x4);
     }
   };
   auto transformA = [&]() {
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       const int pix = tid / KQ + i * PSTEP;
       if (pix < NPIX) {
         const int o = buf * ABUF + (pix / TWIN) * RP + (pix % TWIN) * PITCH + c4 * 4;
-        *reinterpret_cast<bf16x4*>(sAh + o) = qh[i];
-        *reinterpret_cast<bf16x4*>(sAl + o) = ql[i];
+        *reinterpret_cast<x3x4*>(sAh + o) = qh[i];
+        *reinterpret_cast<x3x4*>(sAl + o) = ql[i];
       }
     }
   };
@@ -248,11 +248,11 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     for (int j = 0; j < NW; ++j) {
       const int u = tid + j * NT;
       const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
-      rw[j] = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(p.w) + ((size_t)(k8l * 2 + plane) * p.Npad + n0 + n) * 8 + toff);
+      rw[j] = *reinterpret_cast<const u32x4*>(static_cast<const x3_t*>(p.w) + ((size_t)(k8l * 2 + plane) * p.Npad + n0 + n) * 8 + toff);
     }
   };
   auto storeW = [&](int buf) {
-    __bf16* dst = sW + buf * (TOTW * 8);
+    x3_t* dst = sW + buf * (TOTW * 8);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       *reinterpret_cast<u32x4*>(dst + (tid + j * NT) * 8) = rw[j];
@@ -265,13 +265,13 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
   // (buffer form, dma16 of conv_common.h: SGPR resource at this column tile's first weight, one offset VGPR per lane, the tile as a
   // wave-uniform SGPR offset - next to MFMAs it issues several times faster than the global form with its address VGPR pair)
   const int wrow_b = 2 * p.Npad * 8 * 2;        // BYTES per k8 row pair (hi|lo planes); a layer's packing is a few MB: int offsets
-  const __amdgpu_buffer_rsrc_t rsW = dma_resource(static_cast<const __bf16*>(p.w) + (size_t)n0 * 8);
+  const __amdgpu_buffer_rsrc_t rsW = dma_resource(static_cast<const x3_t*>(p.w) + (size_t)n0 * 8);
   const int vw0 = (((tid / (2 * BN)) * 2 + ((tid / BN) & 1)) * p.Npad + tid % BN) * 16;
   auto gldsW = [&](int chunk, int tap, int buf) {
     const int toff = ((q * TAPS + tap) * K8 + (cbeg + chunk) * 4) * wrow_b;   // q != 0 only for the folded conv
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      __bf16* l = sW + buf * (TOTW * 8) + (wave * 64 + j * NT) * 8;   // wave-uniform base; the hardware adds lane*16 B
+      x3_t* l = sW + buf * (TOTW * 8) + (wave * 64 + j * NT) * 8;   // wave-uniform base; the hardware adds lane*16 B
       dma16(rsW, vw0, toff + j * (NT / (2 * BN)) * wrow_b, l);
     }
   };
@@ -319,32 +319,32 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       loadW(nchunk1, 0);
       loadA(nchunk1);
       const int aoff = (chunk & 1) * ABUF;
-      const __bf16* cW = sW + (chunk & 1) * (TOTW * 8) + wbase;
+      const x3_t* cW = sW + (chunk & 1) * (TOTW * 8) + wbase;
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
-        bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+        x3x8 ah[FM], al[FM], bh[FN], bl[FN];
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm) {
-          ah[fm] = *reinterpret_cast<const bf16x8*>(sAh + aoff + hbase[fm] + s * 16);
-          al[fm] = *reinterpret_cast<const bf16x8*>(sAl + aoff + hbase[fm] + s * 16);
+          ah[fm] = *reinterpret_cast<const x3x8*>(sAh + aoff + hbase[fm] + s * 16);
+          al[fm] = *reinterpret_cast<const x3x8*>(sAl + aoff + hbase[fm] + s * 16);
         }
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) {
-          bh[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s) * BN + fn * 32) * 8);
-          bl[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s + 1) * BN + fn * 32) * 8);
+          bh[fn] = *reinterpret_cast<const x3x8*>(cW + ((4 * s) * BN + fn * 32) * 8);
+          bl[fn] = *reinterpret_cast<const x3x8*>(cW + ((4 * s + 1) * BN + fn * 32) * 8);
         }
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = x3_mfma_32x32x16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
+          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = x3_mfma_32x32x16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+          for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = x3_mfma_32x32x16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
       }
       storeW((chunk + 1) & 1);
       storeA((chunk + 1) & 1);
@@ -382,12 +382,12 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     TR();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+    x3x8 ah[FM], al[FM], bh[FN], bl[FN];
     // LDS byte addresses: one base VGPR per A fragment row set and one for the weights; everything else is an immediate
     unsigned abase[FM];
 #pragma unroll
-    for (int fm = 0; fm < FM; ++fm) abase[fm] = (unsigned)(size_t)(__attribute__((address_space(3))) __bf16*)(sAh + hbase[fm]);
-    const unsigned wb = (unsigned)(size_t)(__attribute__((address_space(3))) __bf16*)(sW + wbase);
+    for (int fm = 0; fm < FM; ++fm) abase[fm] = (unsigned)(size_t)(__attribute__((address_space(3))) x3_t*)(sAh + hbase[fm]);
+    const unsigned wb = (unsigned)(size_t)(__attribute__((address_space(3))) x3_t*)(sW + wbase);
     constexpr int ALO = APLANE * 2;          // byte offset of the lo plane
     constexpr int WSLOT = TOTW * 16;         // bytes per ring slot
     static_assert(ALO + (2 * RP + 2 * PITCH) * 2 + 64 < 65536 && (DYN ? 1 : WRING) * WSLOT < 65536, "LDS immediates must fit 16 bits");
@@ -412,17 +412,17 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
     constexpr int G = FM * FN;
     auto GX = [&](auto&& f) {   // a_lo x w_hi, fm outer: al[fm] is free after its last fn
       static_for<0, FM>([&](auto fm) { static_for<0, FN>([&](auto fn) {
-        acc[fm.value][fn.value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm.value], bh[fn.value], acc[fm.value][fn.value], 0, 0, 0);
+        acc[fm.value][fn.value] = x3_mfma_32x32x16(al[fm.value], bh[fn.value], acc[fm.value][fn.value], 0, 0, 0);
         SB(); f(fm, fn); SB(); }); });
     };
     auto GZ = [&](auto&& f) {   // a_hi x w_hi, fn outer: bh[fn] is free after its last fm
       static_for<0, FN>([&](auto fn) { static_for<0, FM>([&](auto fm) {
-        acc[fm.value][fn.value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm.value], bh[fn.value], acc[fm.value][fn.value], 0, 0, 0);
+        acc[fm.value][fn.value] = x3_mfma_32x32x16(ah[fm.value], bh[fn.value], acc[fm.value][fn.value], 0, 0, 0);
         SB(); f(fm, fn); SB(); }); });
     };
     auto GY = [&](auto&& f) {   // a_hi x w_lo, fm outer: ah[fm] is free after its last fn, the w_lo set after the last MFMA
       static_for<0, FM>([&](auto fm) { static_for<0, FN>([&](auto fn) {
-        acc[fm.value][fn.value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm.value], bl[fn.value], acc[fm.value][fn.value], 0, 0, 0);
+        acc[fm.value][fn.value] = x3_mfma_32x32x16(ah[fm.value], bl[fn.value], acc[fm.value][fn.value], 0, 0, 0);
         SB(); f(fm, fn); SB(); }); });
     };
     // ---- the non-MFMA work of a chunk, in pieces
@@ -451,14 +451,14 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
           ra[i][e] = v;
         }
       } else if (sub == 2) {
-        qh[i] = __builtin_convertvector(ra[i], bf16x4);
+        qh[i] = __builtin_convertvector(ra[i], x3x4);
       } else {
-        ql[i] = __builtin_convertvector(ra[i] - __builtin_convertvector(qh[i], f32x4), bf16x4);
+        ql[i] = __builtin_convertvector(ra[i] - __builtin_convertvector(qh[i], f32x4), x3x4);
       }
     };
     auto gldsWpiece = [&](int chunk, int tap, int buf, int j) {
       const int toff = ((q * TAPS + tap) * K8 + (cbeg + chunk) * 4) * wrow_b;
-      __bf16* l = sW + buf * (TOTW * 8) + (wave * 64 + j * NT) * 8;
+      x3_t* l = sW + buf * (TOTW * 8) + (wave * 64 + j * NT) * 8;
       dma16(rsW, vw0, toff + j * (NT / (2 * BN)) * wrow_b, l);
     };
     if constexpr (PP) {
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       // the MFMAs of a single stream).  A group's barriers are those of the lockstep form (all reads of a slot before its refill, all
       // pieces of a tile landed before its first read); pairing them with the other group's barriers of the other kind changes nothing.
       static_assert(WRING == 3 && TAPS == 9 && NS == 2, "ping-pong loop: ring of 3 over 9 taps");
-      bf16x8 ah2[NS][FM], al2[NS][FM], bh2[NS][FN], bl2[NS][FN];
+      x3x8 ah2[NS][FM], al2[NS][FM], bh2[NS][FN], bl2[NS][FN];
       int woff[NA];   // element offsets of this thread's halo pieces (fixed: the rewrite in tap 8 must not need VALU work)
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
@@ -527,13 +527,13 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
           static_for<0, NS>([&](auto sc_) {
             constexpr int st = decltype(sc_)::value;
             static_for<0, FM>([&](auto fm) { static_for<0, FN>([&](auto fn) {
-              acc[fm.value][fn.value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al2[st][fm.value], bh2[st][fn.value], acc[fm.value][fn.value], 0, 0, 0);
+              acc[fm.value][fn.value] = x3_mfma_32x32x16(al2[st][fm.value], bh2[st][fn.value], acc[fm.value][fn.value], 0, 0, 0);
               SB(); }); });
             static_for<0, FN>([&](auto fn) { static_for<0, FM>([&](auto fm) {
-              acc[fm.value][fn.value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah2[st][fm.value], bh2[st][fn.value], acc[fm.value][fn.value], 0, 0, 0);
+              acc[fm.value][fn.value] = x3_mfma_32x32x16(ah2[st][fm.value], bh2[st][fn.value], acc[fm.value][fn.value], 0, 0, 0);
               SB(); }); });
             static_for<0, FM>([&](auto fm) { static_for<0, FN>([&](auto fn) {
-              acc[fm.value][fn.value] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah2[st][fm.value], bl2[st][fn.value], acc[fm.value][fn.value], 0, 0, 0);
+              acc[fm.value][fn.value] = x3_mfma_32x32x16(ah2[st][fm.value], bl2[st][fn.value], acc[fm.value][fn.value], 0, 0, 0);
               SB(); }); });
           });
           if constexpr (tap == TAPS - 1) {
@@ -541,8 +541,8 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
 #pragma unroll
               for (int i = 0; i < NA; ++i) {
                 if (tid / KQ + i * PSTEP < NPIX) {
-                  *reinterpret_cast<bf16x4*>(sAh + woff[i]) = qh[i];
-                  *reinterpret_cast<bf16x4*>(sAl + woff[i]) = ql[i];
+                  *reinterpret_cast<x3x4*>(sAh + woff[i]) = qh[i];
+                  *reinterpret_cast<x3x4*>(sAl + woff[i]) = ql[i];
                 }
               }
             }
@@ -724,9 +724,9 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
       constexpr int NB1 = BN >= 128 ? 2 : 1;
       constexpr int NA1 = BM * KQ / NT;          // float4 pieces per thread of a 32-channel slab of the tile's own pixels
       static_assert(BM * KQ % NT == 0, "tile pixels must divide over the block");
-      __bf16* a1h = reinterpret_cast<__bf16*>(smem_raw);
-      __bf16* a1l = a1h + NB1 * BM * PITCH;
-      __bf16* w1 = a1l + NB1 * BM * PITCH;        // [NB1 bufs][4 k8][2 planes][BN][8]
+      x3_t* a1h = reinterpret_cast<x3_t*>(smem_raw);
+      x3_t* a1l = a1h + NB1 * BM * PITCH;
+      x3_t* w1 = a1l + NB1 * BM * PITCH;        // [NB1 bufs][4 k8][2 planes][BN][8]
       int goff[NA1];
 #pragma unroll
       for (int i = 0; i < NA1; ++i) {
@@ -749,17 +749,17 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
         for (int j = 0; j < NW; ++j) {
           const int u = tid + j * NT;
           const int k8l = u / (2 * BN), plane = (u / BN) & 1, n = u % BN;
-          rw1[j] = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(p.sw) + ((size_t)((chunk * 4 + k8l) * 2 + plane) * p.Npad + n0 + n) * 8);
+          rw1[j] = *reinterpret_cast<const u32x4*>(static_cast<const x3_t*>(p.sw) + ((size_t)((chunk * 4 + k8l) * 2 + plane) * p.Npad + n0 + n) * 8);
         }
       };
       auto store1 = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA1; ++i) {
-          const bf16x4 hi = __builtin_convertvector(r1[i], bf16x4);
-          const bf16x4 lo = __builtin_convertvector(r1[i] - __builtin_convertvector(hi, f32x4), bf16x4);
+          const x3x4 hi = __builtin_convertvector(r1[i], x3x4);
+          const x3x4 lo = __builtin_convertvector(r1[i] - __builtin_convertvector(hi, f32x4), x3x4);
           const int o = (buf * BM + tid / KQ + i * PSTEP) * PITCH + c4 * 4;
-          *reinterpret_cast<bf16x4*>(a1h + o) = hi;
-          *reinterpret_cast<bf16x4*>(a1l + o) = lo;
+          *reinterpret_cast<x3x4*>(a1h + o) = hi;
+          *reinterpret_cast<x3x4*>(a1l + o) = lo;
         }
 #pragma unroll
         for (int j = 0; j < NW; ++j) *reinterpret_cast<u32x4*>(w1 + buf * (TOTW * 8) + (tid + j * NT) * 8) = rw1[j];
@@ -777,32 +777,32 @@ __global__ __launch_bounds__(KG * NWM * 128, 2) void conv_bf3_kernel(ConvP p) {
         if (chunk + 1 < nch1) load1(chunk + 1);
         const int cur = NB1 == 2 ? ((chunk - ch0) & 1) : 0;
         const int ao = cur * BM * PITCH;
-        const __bf16* cW = w1 + cur * (TOTW * 8) + wbase;
+        const x3_t* cW = w1 + cur * (TOTW * 8) + wbase;
 #pragma unroll
         for (int s2 = 0; s2 < BK / 16; ++s2) {
-          bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+          x3x8 ah[FM], al[FM], bh[FN], bl[FN];
 #pragma unroll
           for (int fm = 0; fm < FM; ++fm) {
-            ah[fm] = *reinterpret_cast<const bf16x8*>(a1h + ao + arow[fm] + s2 * 16);
-            al[fm] = *reinterpret_cast<const bf16x8*>(a1l + ao + arow[fm] + s2 * 16);
+            ah[fm] = *reinterpret_cast<const x3x8*>(a1h + ao + arow[fm] + s2 * 16);
+            al[fm] = *reinterpret_cast<const x3x8*>(a1l + ao + arow[fm] + s2 * 16);
           }
 #pragma unroll
           for (int fn = 0; fn < FN; ++fn) {
-            bh[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s2) * BN + fn * 32) * 8);
-            bl[fn] = *reinterpret_cast<const bf16x8*>(cW + ((4 * s2 + 1) * BN + fn * 32) * 8);
+            bh[fn] = *reinterpret_cast<const x3x8*>(cW + ((4 * s2) * BN + fn * 32) * 8);
+            bl[fn] = *reinterpret_cast<const x3x8*>(cW + ((4 * s2 + 1) * BN + fn * 32) * 8);
           }
 #pragma unroll
           for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = x3_mfma_32x32x16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
 #pragma unroll
           for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
+            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = x3_mfma_32x32x16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
 #pragma unroll
           for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+            for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = x3_mfma_32x32x16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
         }
         if constexpr (NB1 == 1) __syncthreads();   // every wave has read the single buffer
         if (chunk + 1 < nch1) store1(NB1 == 2 ? ((chunk + 1 - ch0) & 1) : 0);

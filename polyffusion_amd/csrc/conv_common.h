@@ -8,7 +8,7 @@
 
 namespace pf {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef x3_t x3x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // LDS fragment read issued as inline asm, NOT as a C++ load: with direct-to-LDS loads in flight the compiler's wait-count
@@ -16,12 +16,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // each ds_read with its MFMA.  The direct-to-LDS pipelines (3x3 loop, planes GEMM, bf16x3 attention) issue their reads here and place counted
 // s_waitcnt lgkmcnt(N) themselves.
 template <int OFF>
-__device__ __forceinline__ bf16x8 lds_read128(unsigned addr) {
+__device__ __forceinline__ x3x8 lds_read128(unsigned addr) {
   u32x4 v;
   constexpr int HI = OFF & ~0xFFFF, LO = OFF & 0xFFFF;   // the instruction's offset field is 16 bits
   if constexpr (HI != 0) addr += HI;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(LO));
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(x3x8, v);
 }
 // Direct-to-LDS copy of 16 bytes per lane in its BUFFER form: SGPR resource (base) + one 32-bit offset VGPR per lane + a wave-uniform
 // SGPR offset, destination = M0-based LDS address + lane * 16.  Next to MFMAs the global form (a 64-bit address VGPR pair per lane)
@@ -232,7 +232,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
   }
   // Destination of a plane-pair tile: the generic out_planes tensor, or - for a q|k|v projection tile that lies inside the
   // Q or the K third - that third's [token][C] plane pair (the V third keeps its transposed layout below).
-  __bf16* pq = static_cast<__bf16*>(p.out_planes);
+  x3_t* pq = static_cast<x3_t*>(p.out_planes);
   size_t pq_plane = (size_t)p.B * p.Hout * p.Wout * p.ld_out;
   int pq_ld = p.ld_out, pq_n0 = p.geglu ? n0 / 2 : n0, pq_n = p.geglu ? p.N / 2 : p.N;
   if (p.qkv) {
@@ -240,7 +240,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
     pq = nullptr;
     if (C % BN == 0 && which < 2) {
       pq_plane = (size_t)p.B * p.Wout * C;
-      pq = static_cast<__bf16*>(p.qkv) + (size_t)(2 * which) * pq_plane;
+      pq = static_cast<x3_t*>(p.qkv) + (size_t)(2 * which) * pq_plane;
       pq_ld = C; pq_n0 = n0 - which * C; pq_n = C;
     }
   }
@@ -250,7 +250,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
     // hi/lo plane output (linear layers only, TH == 1): the finished tile is transposed through LDS as fp32 so that the
     // split and the global stores run row-wise - 16 bytes per lane per plane, whole 128-byte lines - instead of one 2-byte
     // store per element from the column-per-lane accumulator layout.
-    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    typedef x3_t x3x8_t __attribute__((ext_vector_type(8)));
     const int L = p.Wout;
     const int bno = p.geglu ? BN / 2 : BN;         // output columns of this tile
     const int pitch = bno + 8;                     // floats; +8 keeps the two half-waves (rows r, r+4) on different banks
@@ -309,15 +309,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
       const f32x4 a = *reinterpret_cast<const f32x4*>(red + rl * pitch + col) + ra[it];
       const f32x4 c = *reinterpret_cast<const f32x4*>(red + rl * pitch + col + 4) + rc[it];
       // whole-vector conversions: the packed v_cvt_pk_bf16_f32 path (element-wise casts fall back to integer rounding code)
-      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-      const bf16x4_t ha = __builtin_convertvector(a, bf16x4_t), hc = __builtin_convertvector(c, bf16x4_t);
-      const bf16x4_t la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x4), bf16x4_t);
-      const bf16x4_t lc = __builtin_convertvector(c - __builtin_convertvector(hc, f32x4), bf16x4_t);
-      const bf16x8_t hi = __builtin_shufflevector(ha, hc, 0, 1, 2, 3, 4, 5, 6, 7);
-      const bf16x8_t lo = __builtin_shufflevector(la, lc, 0, 1, 2, 3, 4, 5, 6, 7);
+      typedef x3_t x3x4_t __attribute__((ext_vector_type(4)));
+      const x3x4_t ha = __builtin_convertvector(a, x3x4_t), hc = __builtin_convertvector(c, x3x4_t);
+      const x3x4_t la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x4), x3x4_t);
+      const x3x4_t lc = __builtin_convertvector(c - __builtin_convertvector(hc, f32x4), x3x4_t);
+      const x3x8_t hi = __builtin_shufflevector(ha, hc, 0, 1, 2, 3, 4, 5, 6, 7);
+      const x3x8_t lo = __builtin_shufflevector(la, lc, 0, 1, 2, 3, 4, 5, 6, 7);
       const size_t o = ((size_t)b * L + ox0 + rl) * pq_ld + pq_n0 + col;
-      *reinterpret_cast<bf16x8_t*>(pq + o) = hi;
-      *reinterpret_cast<bf16x8_t*>(pq + pq_plane + o) = lo;
+      *reinterpret_cast<x3x8_t*>(pq + o) = hi;
+      *reinterpret_cast<x3x8_t*>(pq + pq_plane + o) = lo;
     }
     return;
   }
@@ -326,12 +326,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
     // time per lane - 8-byte stores scattered over 64 d-rows per instruction.  Transpose the tile through LDS instead
     // ([column][row], so a lane's four consecutive rows are one ds_write_b128) and store token-wise: 16 bytes per lane per
     // plane, 256 contiguous bytes of one d-row per 16 lanes.
-    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    typedef x3_t x3x4_t __attribute__((ext_vector_type(4)));
+    typedef x3_t x3x8_t __attribute__((ext_vector_type(8)));
     constexpr int BM = TW, pitchT = BM + 4;   // floats; +4: the 8 lanes of a b128 write group land on distinct banks
     const int C = p.N / 3, L = p.Wout, H = C / 64;
     const size_t MC = (size_t)p.B * L * C;
-    __bf16* base = static_cast<__bf16*>(p.qkv) + 4 * MC;
+    x3_t* base = static_cast<x3_t*>(p.qkv) + 4 * MC;
     __syncthreads();
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn) {
@@ -356,23 +356,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
       // stored positions 8c..8c+7 of this d-row: the first half of a 16-token block holds source quads 0 and 2, the second 1 and 3
       const float* src = red + cl * pitchT + (c >> 1) * 16 + (c & 1) * 4;
       const f32x4 a = *reinterpret_cast<const f32x4*>(src), q = *reinterpret_cast<const f32x4*>(src + 8);
-      const bf16x4_t ha = __builtin_convertvector(a, bf16x4_t), hq = __builtin_convertvector(q, bf16x4_t);
-      const bf16x4_t la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x4), bf16x4_t);
-      const bf16x4_t lq = __builtin_convertvector(q - __builtin_convertvector(hq, f32x4), bf16x4_t);
+      const x3x4_t ha = __builtin_convertvector(a, x3x4_t), hq = __builtin_convertvector(q, x3x4_t);
+      const x3x4_t la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x4), x3x4_t);
+      const x3x4_t lq = __builtin_convertvector(q - __builtin_convertvector(hq, f32x4), x3x4_t);
       const int cc = n0 - 2 * C + cl;
       const size_t o = (((size_t)b * H + cc / 64) * 64 + cc % 64) * L + ox0 + 8 * c;
-      *reinterpret_cast<bf16x8_t*>(base + o) = __builtin_shufflevector(ha, hq, 0, 1, 2, 3, 4, 5, 6, 7);
-      *reinterpret_cast<bf16x8_t*>(base + MC + o) = __builtin_shufflevector(la, lq, 0, 1, 2, 3, 4, 5, 6, 7);
+      *reinterpret_cast<x3x8_t*>(base + o) = __builtin_shufflevector(ha, hq, 0, 1, 2, 3, 4, 5, 6, 7);
+      *reinterpret_cast<x3x8_t*>(base + MC + o) = __builtin_shufflevector(la, lq, 0, 1, 2, 3, 4, 5, 6, 7);
     }
     return;
   }
   if constexpr (TH == 1) if (p.qkv) {
     // q|k|v planes for the bf16x3 attention: Q,K [token][C] and V^T [head][d][token] (middle token quads of every
     // 16-token block swapped, see attention_bf3.hip), each as a bf16 hi plane and a bf16 lo = bf16(x - hi) plane.
-    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    typedef x3_t x3x4_t __attribute__((ext_vector_type(4)));
     const int C = p.N / 3, L = p.Wout, H = C / 64;
     const size_t MC = (size_t)p.B * L * C;
-    __bf16* base = static_cast<__bf16*>(p.qkv);
+    x3_t* base = static_cast<x3_t*>(p.qkv);
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn) {
       const int n = n0 + wn * WN + fn * 32 + (lane & 31);
@@ -383,19 +383,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
       for (int fm = 0; fm < FM; ++fm) {
         const int tok0 = ox0 + wm * WM + fm * 32;   // first token of this 32-row fragment (dense mode: TH == 1)
         if (which < 2) {
-          __bf16* ph = base + (size_t)(2 * which) * MC + ((size_t)b * L + tok0) * C + cc;
+          x3_t* ph = base + (size_t)(2 * which) * MC + ((size_t)b * L + tok0) * C + cc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (tok0 + row >= L) continue;
             const float v = acc[fm][fn][r] + bn;
-            const __bf16 hi = (__bf16)v;
+            const x3_t hi = (x3_t)v;
             ph[(size_t)row * C] = hi;
-            ph[MC + (size_t)row * C] = (__bf16)(v - (float)hi);
+            ph[MC + (size_t)row * C] = (x3_t)(v - (float)hi);
           }
         } else {
           const int hh = cc / 64, d = cc % 64;
-          __bf16* pv = base + 4 * MC + (((size_t)b * H + hh) * 64 + d) * L;
+          x3_t* pv = base + 4 * MC + (((size_t)b * H + hh) * 64 + d) * L;
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) {
             const int t0 = tok0 + 8 * rq + 4 * (lane >> 5);   // four consecutive tokens held in registers 4rq..4rq+3
@@ -405,11 +405,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
             f32x4 v4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v4[j] = acc[fm][fn][4 * rq + j] + bn;
-            const bf16x4_t hi4 = __builtin_convertvector(v4, bf16x4_t);
-            const bf16x4_t lo4 = __builtin_convertvector(v4 - __builtin_convertvector(hi4, f32x4), bf16x4_t);
+            const x3x4_t hi4 = __builtin_convertvector(v4, x3x4_t);
+            const x3x4_t lo4 = __builtin_convertvector(v4 - __builtin_convertvector(hi4, f32x4), x3x4_t);
             const size_t off = (size_t)(t0 & ~15) + qp * 4;
-            *reinterpret_cast<bf16x4_t*>(pv + off) = hi4;
-            *reinterpret_cast<bf16x4_t*>(pv + MC + off) = lo4;
+            *reinterpret_cast<x3x4_t*>(pv + off) = hi4;
+            *reinterpret_cast<x3x4_t*>(pv + MC + off) = lo4;
           }
         }
       }

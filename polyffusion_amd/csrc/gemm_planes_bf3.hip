@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
   constexpr int STAGE = (AU + WU) * 8;      // bf16 elements per stage
   static_assert(AU % 256 == 0 && WU % 256 == 0, "tile must divide over the block");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);
+  x3_t* sm = reinterpret_cast<x3_t*>(smem_raw);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA destinations (M0) stay in SGPRs
@@ -40,13 +40,13 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
   const int n0 = nti * BN, ox0 = tx * BM;
   const int K = p.c0, L = p.Wout;
   const size_t MK = (size_t)p.B * L * K;
-  const __bf16* A = reinterpret_cast<const __bf16*>(p.x0);
+  const x3_t* A = reinterpret_cast<const x3_t*>(p.x0);
 
   // per-thread byte offsets of the stage pieces inside the workgroup's A rows / W column tile (a chunk adds a wave-uniform offset):
   // buffer-form direct-to-LDS loads (dma16, conv_common.h).  The A resource starts at this sample tile's first row of the hi plane,
   // so every offset stays far below 2 GiB whatever the tensor size.
-  const __bf16* Abase = A + ((size_t)b * L + min(ox0, L - 1)) * K;
-  const __amdgpu_buffer_rsrc_t rsA = dma_resource(Abase), rsW = dma_resource(static_cast<const __bf16*>(p.w) + (size_t)n0 * 8);
+  const x3_t* Abase = A + ((size_t)b * L + min(ox0, L - 1)) * K;
+  const __amdgpu_buffer_rsrc_t rsA = dma_resource(Abase), rsW = dma_resource(static_cast<const x3_t*>(p.w) + (size_t)n0 * 8);
   int va[NAu];
 #pragma unroll
   for (int j = 0; j < NAu; ++j) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
   }
   const int wrow_b = 2 * p.Npad * 8 * 2;      // bytes per k8 row pair (hi|lo planes)
   auto issue = [&](int chunk, int stage) {
-    __bf16* sb = sm + stage * STAGE;
+    x3_t* sb = sm + stage * STAGE;
     const int soa = chunk * BK * 2, sow = chunk * 4 * wrow_b;
 #pragma unroll
     for (int j = 0; j < NAu; ++j) dma16(rsA, va[j], soa, sb + (wave * 64 + j * 256) * 8);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
 
   // LDS byte addresses of this lane's fragments inside a stage.  The swizzled 16-byte slot of K step s is
   // (2s + g) ^ sw = ((g ^ sw) & 1 | sw & 2) ^ 2s, so step 1 is step 0 with bit 1 flipped: two base registers per row set.
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) __bf16*)sm;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) x3_t*)sm;
   const int sw = ((lane & 31) >> 2) & 3;
   const int x0 = (sw & 2) | (((lane >> 5) ^ sw) & 1);
   unsigned abase[FM][2];
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[fm][fn][r] = 0.f;
 
-  bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+  x3x8 ah[FM], al[FM], bh[FN], bl[FN];
   // S = K step (0/1), OFF = byte offset of the ring stage (runtime: added to the base register)
 #define LD_AL(S, OFF) static_for<0, FM>([&](auto i) { al[i.value] = lds_read128<ALO>(abase[i.value][S] + (OFF)); })
 #define LD_AH(S, OFF) static_for<0, FM>([&](auto i) { ah[i.value] = lds_read128<0>(abase[i.value][S] + (OFF)); })
@@ -107,19 +107,19 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(ConvP p) {
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-      for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+      for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = x3_mfma_32x32x16(al[fm], bh[fn], acc[fm][fn], 0, 0, 0);
   };
   auto Z = [&]() {
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-      for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
+      for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = x3_mfma_32x32x16(ah[fm], bh[fn], acc[fm][fn], 0, 0, 0);
   };
   auto Y = [&]() {
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-      for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
+      for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = x3_mfma_32x32x16(ah[fm], bl[fn], acc[fm][fn], 0, 0, 0);
   };
 
   // Same skewed single-fragment-set pipeline as the 3x3 loop of conv_bf16x3.hip: X = a_lo.w_hi, Z = a_hi.w_hi, Y = a_hi.w_lo;

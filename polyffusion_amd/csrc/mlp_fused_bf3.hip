@@ -19,14 +19,14 @@ namespace pf {
 
 struct MlpX {
   const float* gamma; const float* beta; float eps;
-  const __bf16* w1; const float* b1;    // GeGLU projection: bf16x3 packing [K/8][plane][2048][8], columns value|gate interleaved by 32
+  const x3_t* w1; const float* b1;    // GeGLU projection: bf16x3 packing [K/8][plane][2048][8], columns value|gate interleaved by 32
   // TAIL (the SpatialTransformer's proj_out chained on, unet_attention.py:77-79): ff output + residual stay on chip as the A operand of
   // one more 256 x 256 projection; ConvP then describes THAT projection's epilogue (bias, block input as residual, statistics)
   const float* b2;                      // ff.net.2 bias (the ff residual is p.x0, the LayerNorm input)
-  const __bf16* w3;                     // proj_out: bf16x3 packing [32][plane][256][8]
+  const x3_t* w3;                     // proj_out: bf16x3 packing [32][plane][256][8]
 };
 
-typedef __bf16 bf16x4_m __attribute__((ext_vector_type(4)));
+typedef x3_t x3x4_m __attribute__((ext_vector_type(4)));
 
 template <int RING, bool TAIL>
 __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
@@ -111,12 +111,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
       const int row = wave * RPW + i;
       const float rs = 1.0f / sqrtf(red[i] / (float)C + e.eps);
       const f32x4 y = (v[i] - mu[i]) * rs * g + be;
-      const bf16x4_m hi = __builtin_convertvector(y, bf16x4_m);
-      const bf16x4_m lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x4), bf16x4_m);
+      const x3x4_m hi = __builtin_convertvector(y, x3x4_m);
+      const x3x4_m lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x4), x3x4_m);
       // k = 4 lane: chunk = lane / 8, 16-byte slot = (lane % 8) / 2 (XOR-swizzled with the row), half = lane & 1
       unsigned char* d = sA + (lane >> 3) * CH_B + row * 64 + ((((lane & 7) >> 1) ^ ((row >> 2) & 3)) * 16) + (lane & 1) * 8;
-      *reinterpret_cast<bf16x4_m*>(d) = hi;
-      *reinterpret_cast<bf16x4_m*>(d + LO_B) = lo;
+      *reinterpret_cast<x3x4_m*>(d) = hi;
+      *reinterpret_cast<x3x4_m*>(d + LO_B) = lo;
     }
   };
 
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
   // Fragment registers, double-buffered per SLOT: while the MFMAs of slot i run on one set, every fragment of slot i+1 is read into
   // the other (a 16-byte LDS read needs 100-200 cycles to come back; with the per-K-step skew of gemm_planes_bf3.hip this
   // tile's two-MFMA groups gave a read 64-128 cycles of cover and the wave spent more time waiting than multiplying).
-  bf16x8 fal[2][2], fah[2][2], fbh[2][2][2], fbl[2][2][2];   // ff1 slot: [set][K step]([fn])
-  bf16x8 gal[2], gah[2], gbh[2][4], gbl[2][4];                // ff2 slot: [set]([fn])
+  x3x8 fal[2][2], fah[2][2], fbh[2][2][2], fbl[2][2][2];   // ff1 slot: [set][K step]([fn])
+  x3x8 gal[2], gah[2], gbh[2][4], gbl[2][4];                // ff2 slot: [set]([fn])
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define IC(N) std::integral_constant<int, (N)>{}
 #define FROM_H std::false_type{}
@@ -169,15 +169,15 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
   // n-th MFMA of a slot: per K step X X Z Z Y Y (ff1, two column fragments) / X X X X Z Z Z Z Y Y Y Y (ff2, four)
   auto mf1 = [&](auto S_, auto N_) {
     constexpr int S = S_.value, ks = N_.value / 6, m = N_.value % 6, fn = m & 1;
-    if constexpr (m < 2) acc1[fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[S][ks], fbh[S][ks][fn], acc1[fn], 0, 0, 0);
-    else if constexpr (m < 4) acc1[fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[S][ks], fbh[S][ks][fn], acc1[fn], 0, 0, 0);
-    else acc1[fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[S][ks], fbl[S][ks][fn], acc1[fn], 0, 0, 0);
+    if constexpr (m < 2) acc1[fn] = x3_mfma_32x32x16(fal[S][ks], fbh[S][ks][fn], acc1[fn], 0, 0, 0);
+    else if constexpr (m < 4) acc1[fn] = x3_mfma_32x32x16(fah[S][ks], fbh[S][ks][fn], acc1[fn], 0, 0, 0);
+    else acc1[fn] = x3_mfma_32x32x16(fah[S][ks], fbl[S][ks][fn], acc1[fn], 0, 0, 0);
   };
   auto mf2 = [&](auto S_, auto N_) {
     constexpr int S = S_.value, g = N_.value / 4, fn = N_.value % 4;
-    if constexpr (g == 0) acc2[0][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gal[S], gbh[S][fn], acc2[0][fn], 0, 0, 0);
-    else if constexpr (g == 1) acc2[0][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gah[S], gbh[S][fn], acc2[0][fn], 0, 0, 0);
-    else acc2[0][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gah[S], gbl[S][fn], acc2[0][fn], 0, 0, 0);
+    if constexpr (g == 0) acc2[0][fn] = x3_mfma_32x32x16(gal[S], gbh[S][fn], acc2[0][fn], 0, 0, 0);
+    else if constexpr (g == 1) acc2[0][fn] = x3_mfma_32x32x16(gah[S], gbh[S][fn], acc2[0][fn], 0, 0, 0);
+    else acc2[0][fn] = x3_mfma_32x32x16(gah[S], gbl[S][fn], acc2[0][fn], 0, 0, 0);
   };
   // Slot hand-over of slot i, in two halves.  FRAGS_READY (before MFMA 0): every fragment of slot i has arrived in its registers.
   // SLOT_SYNC (after MFMA 1, so that the matrix pipe has work while the barrier resolves): this thread's pieces of slot i+1 have
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
   float bv = 0.f, bg = 0.f, bvn, bgn;
   float tz[16], tt[16], tq[16];
   f32x4 hq[4];
-  bf16x4_m hhi[4], hlo[4];
+  x3x4_m hhi[4], hlo[4];
   f32x4 spl = {0.f, 0.f, 0.f, 0.f};   // scratch of the hi/lo split with registers of its own for the whole kernel (kept live below): as an ordinary temporary it
                                       // landed in the A-fragment registers of the MFMA just issued, and a VALU write to a register the matrix pipe is still reading stalls
   unsigned hdst[4];   // LDS byte address of this lane's 8-byte piece of the product, one per 8-row group q (hi plane; lo = + LO_B)
@@ -242,8 +242,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
       const float k0 = hq[q][lo], k1 = hq[q][lo + 2];
       hq[q][lo] = lp2 ? rv : k0; hq[q][lo + 2] = lp2 ? k1 : rv;
       // now lane j of a quad holds row 8q + 4(lane>>5) + j, hidden units 4*((lane&31)>>2) .. +3 of this wave's 32
-    } else if constexpr (i == 16) hhi[q] = __builtin_convertvector(hq[q], bf16x4_m);
-    else if constexpr (i == 17) { spl = __builtin_convertvector(hhi[q], f32x4); spl = hq[q] - spl; hlo[q] = __builtin_convertvector(spl, bf16x4_m); asm volatile("" : "+v"(spl)); }
+    } else if constexpr (i == 16) hhi[q] = __builtin_convertvector(hq[q], x3x4_m);
+    else if constexpr (i == 17) { spl = __builtin_convertvector(hhi[q], f32x4); spl = hq[q] - spl; hlo[q] = __builtin_convertvector(spl, x3x4_m); asm volatile("" : "+v"(spl)); }
     else {
       typedef unsigned u32x2_m __attribute__((ext_vector_type(2)));
       const unsigned dd = hdst[q];   // (locals: clang does not capture a variable that a lambda names only in an asm operand)
@@ -422,11 +422,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
           f32x4 v = {acc2[0][fn][4 * q], acc2[0][fn][4 * q + 1], acc2[0][fn][4 * q + 2], acc2[0][fn][4 * q + 3]};
           quad_transpose(v, lane);
           v = PF_X3_UNSCALE(v) + (b4[fn] + r4[fn]);        // acc + (bias + residual): the order of conv_epilogue's plane-pair path, which this replaces
-          const bf16x4_m hi = __builtin_convertvector(v, bf16x4_m);
-          const bf16x4_m lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), bf16x4_m);
+          const x3x4_m hi = __builtin_convertvector(v, x3x4_m);
+          const x3x4_m lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), x3x4_m);
           unsigned char* d = sA + (wn * 4 + fn) * CH_B + row * 64 + (((cq >> 3) ^ ((row >> 2) & 3)) * 16) + ((cq >> 2) & 1) * 8;
-          *reinterpret_cast<bf16x4_m*>(d) = hi;
-          *reinterpret_cast<bf16x4_m*>(d + LO_B) = lo;
+          *reinterpret_cast<x3x4_m*>(d) = hi;
+          *reinterpret_cast<x3x4_m*>(d + LO_B) = lo;
         }
       }
 #pragma unroll
@@ -473,7 +473,7 @@ int launch_mlp_fused(const float* x, int batch, int l, const float* gamma, const
   p.ksplit = 1;
   p.tiles_x = l / 64; p.tiles_y = 1; p.nt = 1;
   conv_fill_divs(p);
-  MlpX e{gamma, beta, eps, static_cast<const __bf16*>(w1), b1, b2, static_cast<const __bf16*>(w3)};
+  MlpX e{gamma, beta, eps, static_cast<const x3_t*>(w1), b1, b2, static_cast<const x3_t*>(w3)};
   constexpr size_t main_b = 65536 + RING * 16384 + 16384 + 8192;
   constexpr size_t epi_b = 65536 + (size_t)64 * (256 + 8) * 4;   // planes output: the fp32 tile is transposed through the ring region
   constexpr size_t lds = main_b > epi_b ? main_b : epi_b;

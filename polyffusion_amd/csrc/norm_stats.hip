@@ -161,10 +161,10 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__
 // LayerNorm applied and split into the bf16 hi/lo planes a planes GEMM (gemm_planes_bf3.hip) streams straight into LDS:
 // y = (x - mean) * rstd * gamma + beta, same operation order as the GEMM-prologue form.  One wave per row, the row stays
 // in registers between the statistics and the output (C <= 1024), so x is read once: 4 B in, 4 B out per element.
-typedef __bf16 bf16x4_n __attribute__((ext_vector_type(4)));
+typedef x3_t x3x4_n __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void ln_planes_kernel(const float* __restrict__ x, int rows, int C, float eps,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        __bf16* __restrict__ planes) {
+                                                        x3_t* __restrict__ planes) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -196,10 +196,10 @@ __global__ __launch_bounds__(256) void ln_planes_kernel(const float* __restrict_
     if (k < C) {
       const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + k), be = *reinterpret_cast<const f32x4*>(beta + k);
       const f32x4 y = (v[i] - mu) * rs * g + be;
-      const bf16x4_n hi = __builtin_convertvector(y, bf16x4_n);
-      const bf16x4_n lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x4), bf16x4_n);
-      *reinterpret_cast<bf16x4_n*>(planes + (size_t)row * C + k) = hi;
-      *reinterpret_cast<bf16x4_n*>(planes + MC + (size_t)row * C + k) = lo;
+      const x3x4_n hi = __builtin_convertvector(y, x3x4_n);
+      const x3x4_n lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x4), x3x4_n);
+      *reinterpret_cast<x3x4_n*>(planes + (size_t)row * C + k) = hi;
+      *reinterpret_cast<x3x4_n*>(planes + MC + (size_t)row * C + k) = lo;
     }
   }
 }
@@ -208,7 +208,7 @@ int launch_ln_planes(const float* x, int rows, int c, float eps, const float* ga
                      hipStream_t stream) {
   PF_REQUIRE(x && gamma && beta && planes && rows > 0 && c > 0 && c % 4 == 0 && c <= 1024, "ln_planes: bad arguments (c=%d)", c);
   hipLaunchKernelGGL(ln_planes_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, rows, c, eps, gamma, beta,
-                     static_cast<__bf16*>(planes));
+                     static_cast<x3_t*>(planes));
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }

@@ -149,14 +149,16 @@ int launch_txt_frontend(const float* pr, const float* w, const float* bias, floa
 // product, paid for with fp16's range - |activation| must stay below 65504 and pieces below 6e-5 lose bits (fp16 subnormals ARE honoured by
 // the matrix pipe, tools/micro/f16x3_probe.hip).  Weights are small numbers (|w| ~ 0.03 puts the lo piece deep in the subnormals), so that
 // build packs them times PF_X3_WS = 2^8 and every epilogue takes its accumulators times 2^-8 - exact, and folded into the bias add as an fma.
-// The element type is spelled __bf16 throughout the kernels; the f16 build renames it here, after every system header has been read.
+// The kernels spell the element type x3_t, its vectors x3x2 / x3x4 / x3x8 (typedef'd where they are used) and the MFMA x3_mfma_32x32x16.
 #ifdef PF_X3_F16
-#define __bf16 _Float16
-#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+typedef _Float16 x3_t;
+#define x3_mfma_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
 #define PF_X3_WS 256.0f
 #define PF_X3_WS_INV 0.00390625f
 #define PF_X3_UNSCALE(a) ((a) * PF_X3_WS_INV)
 #else
+typedef __bf16 x3_t;
+#define x3_mfma_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
 #define PF_X3_WS 1.0f
 #define PF_X3_WS_INV 1.0f
 #define PF_X3_UNSCALE(a) (a)

@@ -20,13 +20,13 @@
 namespace pf {
 
 struct PreX {
-  const __bf16* w_in; const float* b_in;   // proj_in: bf16x3 packing [32][plane][256][8], bias [256]
+  const x3_t* w_in; const float* b_in;   // proj_in: bf16x3 packing [32][plane][256][8], bias [256]
   float* y;                                 // proj_in output, fp32 [B*L][256]
   const float* gamma; const float* beta; float eps;   // LayerNorm1
-  const __bf16* w_qkv;                      // to_q | to_k | to_v: bf16x3 packing [32][plane][768][8]
+  const x3_t* w_qkv;                      // to_q | to_k | to_v: bf16x3 packing [32][plane][768][8]
 };
 
-typedef __bf16 bf16x4_p __attribute__((ext_vector_type(4)));
+typedef x3_t x3x4_p __attribute__((ext_vector_type(4)));
 
 // cycle stamps of workgroup 0 (tools/trace_pre.py builds a -DPF_PRE_TRACE copy; the buffer pointer travels in ConvP::mean, unused here)
 #ifdef PF_PRE_TRACE
@@ -92,12 +92,12 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
     for (int i = 0; i < RPW; ++i) {
       const int row = wave * RPW + i;
       const f32x4 y = v[i] * sc + sh;
-      const bf16x4_p hi = __builtin_convertvector(y, bf16x4_p);
-      const bf16x4_p lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x4), bf16x4_p);
+      const x3x4_p hi = __builtin_convertvector(y, x3x4_p);
+      const x3x4_p lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x4), x3x4_p);
       // k = 4 lane: chunk = lane / 8, 16-byte slot = (lane % 8) / 2 (XOR-swizzled with the row), half = lane & 1
       unsigned char* d = sA + (lane >> 3) * CH_B + row * 64 + ((((lane & 7) >> 1) ^ ((row >> 2) & 3)) * 16) + (lane & 1) * 8;
-      *reinterpret_cast<bf16x4_p*>(d) = hi;
-      *reinterpret_cast<bf16x4_p*>(d + LO_B) = lo;
+      *reinterpret_cast<x3x4_p*>(d) = hi;
+      *reinterpret_cast<x3x4_p*>(d + LO_B) = lo;
     }
   }
 
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][i][r] = 0.f;
-  bf16x8 gal[2], gah[2], gbh[2][4], gbl[2][4];   // fragments, double-buffered per slot
+  x3x8 gal[2], gah[2], gbh[2][4], gbl[2][4];   // fragments, double-buffered per slot
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define IC(N) std::integral_constant<int, (N)>{}
   // n-th fragment read of step CC (ring position RP) into set S: n = 0..3 w_hi, 4..7 w_lo, 8 a_lo, 9 a_hi
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
   // n-th MFMA of a slot: X X X X (a_lo.w_hi)  Z Z Z Z (a_hi.w_hi)  Y Y Y Y (a_hi.w_lo) over the wave's four column fragments
   auto mf = [&](auto S_, auto N_) {
     constexpr int S = S_.value, g = N_.value / 4, fn = N_.value % 4;
-    if constexpr (g == 0) acc[0][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gal[S], gbh[S][fn], acc[0][fn], 0, 0, 0);
-    else if constexpr (g == 1) acc[0][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gah[S], gbh[S][fn], acc[0][fn], 0, 0, 0);
-    else acc[0][fn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gah[S], gbl[S][fn], acc[0][fn], 0, 0, 0);
+    if constexpr (g == 0) acc[0][fn] = x3_mfma_32x32x16(gal[S], gbh[S][fn], acc[0][fn], 0, 0, 0);
+    else if constexpr (g == 1) acc[0][fn] = x3_mfma_32x32x16(gah[S], gbh[S][fn], acc[0][fn], 0, 0, 0);
+    else acc[0][fn] = x3_mfma_32x32x16(gah[S], gbl[S][fn], acc[0][fn], 0, 0, 0);
   };
 #define FRAGS_READY() do { SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SB(); } while (0)
 #define SLOT_SYNC() do { SB(); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); SB(); } while (0)
@@ -245,11 +245,11 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
       const int row = wave * RPW + i;
       const float rs = 1.0f / sqrtf(red[i] / (float)C + e.eps);
       const f32x4 y = (v[i] - mu[i]) * rs * g + be;
-      const bf16x4_p hi = __builtin_convertvector(y, bf16x4_p);
-      const bf16x4_p lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x4), bf16x4_p);
+      const x3x4_p hi = __builtin_convertvector(y, x3x4_p);
+      const x3x4_p lo = __builtin_convertvector(y - __builtin_convertvector(hi, f32x4), x3x4_p);
       unsigned char* d = sA + (lane >> 3) * CH_B + row * 64 + ((((lane & 7) >> 1) ^ ((row >> 2) & 3)) * 16) + (lane & 1) * 8;
-      *reinterpret_cast<bf16x4_p*>(d) = hi;
-      *reinterpret_cast<bf16x4_p*>(d + LO_B) = lo;
+      *reinterpret_cast<x3x4_p*>(d) = hi;
+      *reinterpret_cast<x3x4_p*>(d + LO_B) = lo;
     }
     // (the pass's own opening wait + barrier publishes the planes; the fp32 rows v[] go to HBM at the very end of the kernel: stores
     // issued here would sit in the same counter as the weight copies and every slot hand-over would wait for the write burst)
@@ -264,21 +264,21 @@ __global__ __launch_bounds__(256, 1) void preattn_bf3_kernel(ConvP p, PreX e) {
   // same conversions: the planes are bit-identical to the staged writer's.
   auto store_qk = [&](int which) {
     const size_t MC = (size_t)p.B * L * C;
-    __bf16* ph = static_cast<__bf16*>(p.qkv) + (size_t)(2 * which) * MC;
+    x3_t* ph = static_cast<x3_t*>(p.qkv) + (size_t)(2 * which) * MC;
     const int cq = (lane & 31) & ~3;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = wm * 32 + 8 * q + 4 * (lane >> 5) + (lane & 3);
-      __bf16* pr = ph + (row0 + row) * C + wn * 128 + cq;
+      x3_t* pr = ph + (row0 + row) * C + wn * 128 + cq;
 #pragma unroll
       for (int fn = 0; fn < 4; ++fn) {
         f32x4 t = {acc[0][fn][4 * q], acc[0][fn][4 * q + 1], acc[0][fn][4 * q + 2], acc[0][fn][4 * q + 3]};
         quad_transpose(t, lane);
         t = PF_X3_UNSCALE(t);
-        const bf16x4_p hi = __builtin_convertvector(t, bf16x4_p);
-        const bf16x4_p lo = __builtin_convertvector(t - __builtin_convertvector(hi, f32x4), bf16x4_p);
-        *reinterpret_cast<bf16x4_p*>(pr + fn * 32) = hi;
-        *reinterpret_cast<bf16x4_p*>(pr + MC + fn * 32) = lo;
+        const x3x4_p hi = __builtin_convertvector(t, x3x4_p);
+        const x3x4_p lo = __builtin_convertvector(t - __builtin_convertvector(hi, f32x4), x3x4_p);
+        *reinterpret_cast<x3x4_p*>(pr + fn * 32) = hi;
+        *reinterpret_cast<x3x4_p*>(pr + MC + fn * 32) = lo;
       }
     }
 #pragma unroll
@@ -343,7 +343,7 @@ int launch_preattn_fused(const float* x, int batch, int l, float* sc, float* sh,
 #ifdef PF_PRE_TRACE
   if (const char* tp = getenv("PF_TRACE_PTR")) p.mean = reinterpret_cast<const float*>(strtoull(tp, nullptr, 16));
 #endif
-  PreX e{static_cast<const __bf16*>(w_in), b_in, y, ln_gamma, ln_beta, ln_eps, static_cast<const __bf16*>(w_qkv)};
+  PreX e{static_cast<const x3_t*>(w_in), b_in, y, ln_gamma, ln_beta, ln_eps, static_cast<const x3_t*>(w_qkv)};
   constexpr size_t lds = 65536 + RING * 16384 + 8192;
   static_assert(lds <= 160 * 1024 && RING * 16384 + 8192 >= 256 * (64 + 4) * 4 && RING * 16384 + 8192 >= 64 * (256 + 8) * 4, "LDS budget / epilogue staging");
   static std::atomic<uint64_t> done{0};
