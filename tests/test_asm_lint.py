@@ -13,16 +13,15 @@ sys.path.insert(0, REPO)
 
 
 @pytest.mark.skipif(shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) is None, reason="needs hipcc")
-@pytest.mark.parametrize("variant", ["", "f16"])
-def test_no_instruction_touches_a_register_with_a_hidden_load_in_flight(capsys, variant):
+def test_no_instruction_touches_a_register_with_a_hidden_load_in_flight(capsys):
     """Both builds of the split kernels (bf16 pieces; fp16 pieces, -DPF_X3_F16): the register allocation differs, the hazard is the same."""
     from tools import lint_asm
-    rc = lint_asm.main([f"--variant={variant}"])
+    rc = lint_asm.main(["--variant=", "--variant=f16"])
     out = capsys.readouterr().out
     assert rc == 0 and "lint_asm: clean" in out, out[-3000:]
     # every kernel family was actually analysed
     for name in ("conv_bf3_kernelILi3", "conv_bf3_kernelILi2", "gemm_planes_kernel", "attn_bf3_kernel"):
-        assert name in out
+        assert out.count(name) >= 2            # once per build
 
 
 def test_lint_flags_the_round2_hazard():

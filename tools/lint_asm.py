@@ -163,16 +163,18 @@ def lint_file(path: str) -> int:
     return n_bad
 
 
-def compile_to_asm(variant: str = "") -> list:
-    out_dir = os.path.join(REPO, "build", "asm" + ("_" + variant if variant else ""))
-    os.makedirs(out_dir, exist_ok=True)
+def compile_to_asm(variants=("",)) -> list:
+    """hipcc -S of every linted source for every variant asked for, all processes side by side."""
     procs, outs = [], []
-    for src in SOURCES:
-        out = os.path.join(out_dir, src.replace(".hip", ".s"))
-        outs.append(out)
-        procs.append(subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                                       "-Wno-unused-command-line-argument"] + EXTRA_FLAGS.get(src, []) + VARIANTS[variant] +
-                                      [os.path.join(REPO, "polyffusion_amd", "csrc", src), "-o", out]))
+    for variant in variants:
+        out_dir = os.path.join(REPO, "build", "asm" + ("_" + variant if variant else ""))
+        os.makedirs(out_dir, exist_ok=True)
+        for src in SOURCES:
+            out = os.path.join(out_dir, src.replace(".hip", ".s"))
+            outs.append(out)
+            procs.append(subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                                           "-Wno-unused-command-line-argument"] + EXTRA_FLAGS.get(src, []) + VARIANTS[variant] +
+                                          [os.path.join(REPO, "polyffusion_amd", "csrc", src), "-o", out]))
     for p in procs:
         if p.wait() != 0:
             raise SystemExit("hipcc failed")
@@ -182,7 +184,7 @@ def compile_to_asm(variant: str = "") -> list:
 def main(argv) -> int:
     variants = [a.split("=", 1)[1] for a in argv if a.startswith("--variant=")]
     argv = [a for a in argv if not a.startswith("--variant=")]
-    files = argv or [f for v in (variants or [""]) for f in compile_to_asm(v)]
+    files = argv or compile_to_asm(variants or [""])
     total = sum(lint_file(f) for f in files)
     print("lint_asm:", "clean" if total == 0 else f"{total} violation(s)")
     return 1 if total else 0
