@@ -138,7 +138,8 @@ class DataSample:
 # ---- validation-set song files (ref:data/dataset.py:27-253, data/dataset_musicalion.py:25-208) ----------------------------------------
 # PARITY UNPINNED: the POP909 / Musicalion .npz collections are not part of the reference checkout (only the split lists under
 # data/train_split_pnt/ are) and no fixture of the reference holds one of their files; the classes below restate the reference's
-# loaders for the file layout those loaders document, and are tested on synthetic files of that layout.
+# loaders for the file layout those loaders read; tests/test_datasample.py holds them, bit for bit, to what the REAL reference loaders
+# returned on synthetic files of that layout (tests/golden/dataset.npz, tools/make_goldens_dataset.py).
 POP909_DATA_DIR = "data/POP909_4_bin_pnt_8bar"              # ref:dirs.py:8-9
 MUSICALION_DATA_DIR = "data/musicalion_solo_piano_4_bin_pnt"
 TRAIN_SPLIT_DIR = "data/train_split_pnt"                    # ref:dirs.py:5

@@ -69,7 +69,7 @@ def _pop909_file(tmp_path, seed=0):
 
 
 def test_pop909_song_file_tracks(tmp_path):
-    """DataSampleNpz (ref:data/dataset.py:27-253; parity unpinned - the dataset is not shipped): one track alone equals DataSample on
+    """DataSampleNpz (ref:data/dataset.py:27-253; pinned against the reference loader further down): one track alone equals DataSample on
     that track's rows, several tracks give the union of their piano rolls, and the validation half of the split pickle is what
     --from_dataset indexes (ref:inference_sdf.py:95-105)."""
     from polyffusion_amd import datasample as ds
@@ -107,3 +107,62 @@ def test_split_pickle_admits_only_name_lists(tmp_path):
     if os.path.exists(ref):
         tr, va = ds.load_split(ref)
         assert len(tr) == 797 and len(va) == 89 and va[0] == "258.npz"
+
+
+# ---------------------------------------------------------------------------------------------- dataset loaders, pinned
+def _dataset_files(tmp_path):
+    import dataset_fixture as fx
+    fx.write_all(str(tmp_path / "pop"), str(tmp_path / "mus"), str(tmp_path / "split"))
+    return fx
+
+
+DG = np.load(os.path.join(os.path.dirname(__file__), "golden", "dataset.npz"))
+
+
+def _same(got, want):
+    got = got.numpy() if hasattr(got, "numpy") else np.asarray(got)
+    return got.shape == want.shape and np.array_equal(got.astype(np.int64) if want.dtype == np.int16 else got, want.astype(np.int64) if want.dtype == np.int16 else want)
+
+
+def test_pop909_loader_against_the_reference_loader_on_the_same_files(tmp_path):
+    """tests/golden/dataset.npz holds what the REAL ref:data/dataset.py DataSampleNpz returned for the synthetic song files of
+    tests/dataset_fixture.py (tools/make_goldens_dataset.py): three tracks in four selections (the rows of the chosen tracks one after
+    the other, in the order given), a song whose start tables end inside the last segment (`notes[s_ind:]`), whose chords run out
+    (zero rows appended), with a silent stretch (an empty segment) and an irregular downbeat grid, and a single-matrix file.  Bit-exact."""
+    from polyffusion_amd import datasample as ds
+    fx = _dataset_files(tmp_path)
+    n = 0
+    for fn, (kind_ds, seed, kind) in fx.SONGS.items():
+        if kind_ds != "pop909":
+            continue
+        for tracks in ([(0, 1, 2), (0,), (2, 0), (1,)] if kind != "single" else [(0, 1, 2)]):
+            tag = f"{fn[:-4]}_t{''.join(map(str, tracks))}"
+            song = ds.DataSampleNpz(fn, tracks, str(tmp_path / "pop"))
+            assert len(song) == int(DG[f"{tag}_len"])
+            p2, pn, ch, pm = song.get_whole_song_data()
+            assert p2.dtype == torch.float32 and pn.dtype == torch.int64 and ch.dtype == torch.float32 and pm.dtype == torch.float32
+            assert _same(p2, DG[f"{tag}_prmat2c"]) and _same(pn, DG[f"{tag}_pnotree"]) and _same(ch, DG[f"{tag}_chord"]) and _same(pm, DG[f"{tag}_prmat"]), tag
+            for i in (0, len(song) - 1):
+                it = song[i]
+                assert _same(it[0], DG[f"{tag}_item{i}_prmat2c"]) and _same(it[1], DG[f"{tag}_item{i}_pnotree"]), (tag, i)
+                assert _same(it[2], DG[f"{tag}_item{i}_chord"]) and _same(it[3], DG[f"{tag}_item{i}_prmat"]), (tag, i)
+            n += 1
+    assert n == 9
+    # --from_dataset indexes the validation half of the split (ref:inference_sdf.py:95-105)
+    song, fn = ds.choose_song_from_val_dl("pop909", 1, (0, 1, 2), str(tmp_path / "pop"), str(tmp_path / "split"))
+    assert fn == "pop_ragged.npz" and _same(song.get_whole_song_data()[0], DG["pop_ragged_t012_prmat2c"])
+
+
+def test_musicalion_loader_against_the_reference_loader_on_the_same_file(tmp_path):
+    """ref:data/dataset_musicalion.py DataSampleNpz_Musicalion on the synthetic file (start table ending inside the last segment, one
+    filtered downbeat): same piano rolls and piano-tree grid, bit for bit; no chord track."""
+    from polyffusion_amd import datasample as ds
+    _dataset_files(tmp_path)
+    song, fn = ds.choose_song_from_val_dl("musicalion", 0, data_dir=str(tmp_path / "mus"), split_dir=str(tmp_path / "split"))
+    assert fn == "mus_a.npz" and len(song) == int(DG["mus_a_len"])
+    res = song.get_whole_song_data()
+    assert res[2] is None
+    assert _same(res[0], DG["mus_a_prmat2c"]) and _same(res[1], DG["mus_a_pnotree"]) and _same(res[3], DG["mus_a_prmat"])
+    for i in (0, len(song) - 1):
+        it = song[i]
+        assert _same(it[0], DG[f"mus_a_item{i}_prmat2c"]) and _same(it[1], DG[f"mus_a_item{i}_pnotree"]) and _same(it[3], DG[f"mus_a_item{i}_prmat"])
