@@ -266,6 +266,10 @@ int pf_pack_gemm_weight(const float* w, int n, int k, int taps, float* dst);
 int pf_pack_gemm_weight_bf16x3(const float* w, int n, int k, int taps, void* dst);
 /* [n][k][3][3] conv weight of an UpSample layer -> folded packing [4 parities x 4 taps][k/8][plane][Npad][8] (host; k % 8 == 0) */
 int pf_pack_upfold_weight_bf16x3(const float* w, int n, int k, void* dst);
+/* Winograd F(2x2, 3x3) packing of a 3x3 conv weight [n][k][3][3] (n %% 64 == 0, k %% 16 == 0) for pf_conv_args.w_wino: U = G g G^T per (n, k),
+ * split into hi | lo pieces, laid out in matrix-operand order; pf_wino_weight_bytes(n, k) = 16 * k * n * 4 bytes */
+size_t pf_wino_weight_bytes(int n, int k);
+int pf_pack_wino_weight_bf16x3(const float* w, int n, int k, void* dst);
 
 /* GroupNorm statistics on NHWC (optionally the channel-concat of two tensors) -> per-(b,c)
  * scale/shift so that y = x*scale + shift equals GroupNorm(x) (unet.py:321-336; eps 1e-5 / 1e-6). */
@@ -356,6 +360,11 @@ typedef struct pf_conv_args {
   /* > 0: the SECOND sources (x1, skip_x1, gn_stats1) hold only x1_bmod samples; sample b reads sample b %% x1_bmod of them (the shared skip
    * tensors of pf_unet_forward_cfg) */
   int32_t x1_bmod;
+  /* Fused Winograd F(2x2, 3x3) form of the ResBlock conv (bf16x3, ks = 3, stride 1, prologue 1, hin / win multiples of 16, n a multiple
+   * of 64, no fused skip projection): w_wino = the layer's weights transformed and packed by pf_pack_wino_weight_bf16x3; wino != 0 asks for it.
+   * 2.25x fewer matrix-pipe operations; equal to the direct form up to rounding (the transforms amplify the split's operand rounding
+   * ~1.5x, tools/micro/winograd_numerics.py).  A launch that does not qualify runs the direct form on `w`. */
+  const void* w_wino; int32_t wino;
 } pf_conv_args;
 /* scratch bytes a launch with these arguments would like for split-K (0 = the launch does not split) */
 size_t pf_conv_splitk_ws_bytes(const pf_conv_args* a);

@@ -88,6 +88,7 @@ class ConvArgs(C.Structure):
         ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float), ("gn_groups", C.c_int32),
         ("sbias_rows", C.c_void_p), ("sbias_nrows", C.c_int32), ("no_t16", C.c_int32), ("no_pp", C.c_int32),
         ("force_tile", C.c_int32), ("force_ksplit", C.c_int32), ("x1_bmod", C.c_int32),
+        ("w_wino", C.c_void_p), ("wino", C.c_int32),
     ]
 
 
@@ -156,6 +157,8 @@ SIGNATURES = {
     "pf_pack_gemm_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pf_pack_gemm_weight_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pf_pack_upfold_weight_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pf_wino_weight_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "pf_pack_wino_weight_bf16x3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pf_unet_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_unet_get_precision": (C.c_int, [C.c_void_p]),
     "pf_x3_element": (C.c_int, []),

@@ -943,6 +943,7 @@ static int dispatch_tile3(ConvP& p, int tile, hipStream_t s) {
 
 // same argument validation as launch_conv (done by the caller); w points to the bf16x3 packing
 int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
+  if (conv_wino_eligible(a)) return launch_conv_wino(a, stream);
   ConvP p;
   memset(&p, 0, sizeof p);
   p.x0 = a.x0; p.x1 = a.x1; p.c0 = a.c0; p.c1 = a.c1;

@@ -269,7 +269,7 @@ void conv_tile_shape(const pf_conv_args& a, int tile, int* th, int* tw) {
 // split-K (bf16x3 3x3 only): layers whose tile grid cannot fill the chip (the 16x16 level at batch 16, most levels at
 // small batch) run ksplit K-slices per tile and a reduce kernel that also applies the epilogue
 static int ksplit_wanted(const pf_conv_args& a) {
-  if (a.precision != PF_PREC_BF16X3 || a.ks != 3 || a.stride != 1 || a.geglu || a.ups_fold) return 1;
+  if (a.precision != PF_PREC_BF16X3 || a.ks != 3 || a.stride != 1 || a.geglu || a.ups_fold || conv_wino_eligible(a)) return 1;
   int hout, wout, th, tw;
   conv_out_dims(a, &hout, &wout);
   if ((hout * wout) % 64 != 0) return 1;
@@ -299,6 +299,7 @@ int conv_ksplit(const pf_conv_args& a) {
 int conv_stats_tiles(const pf_conv_args& a) {
   int hout, wout, th, tw;
   conv_out_dims(a, &hout, &wout);
+  if (conv_wino_eligible(a)) return (hout / 16) * (wout / 16);   // the Winograd form: one statistics tile per 16x16-pixel workgroup
   if (conv_ksplit(a) > 1) return hout * wout / 64;   // the reduce kernel emits one statistics tile per 64 rows
   conv_tile_shape(a, conv_pick_tile(a), &th, &tw);
   if (a.ups_fold) return cdiv(a.hin, th) * cdiv(a.win, tw) * 4;   // tiles walk the source grid, one statistics tile per parity

@@ -55,6 +55,10 @@ size_t conv_splitk_ws_bytes(const pf_conv_args& a);              // scratch want
 // both return false when a weight does not fit the split's element type (fp16 build: |w| * 2^8 > 65504; the packing then holds the clamped value)
 bool pack_gemm_bf3(void* dst, const float* src, int n_src, int K, int taps, int Npad, int n_off, const int* colmap);
 bool pack_upfold_bf3(void* dst, const float* src, int N, int K, int Npad);   // UpSample conv weight -> 4 parities x 4 taps
+// fused Winograd F(2x2, 3x3) form of the stride-1 3x3 conv (conv_wino.hip): eligibility of a launch, the launch, the weight transform + packing
+bool conv_wino_eligible(const pf_conv_args& a);
+int launch_conv_wino(const pf_conv_args& a, hipStream_t stream);
+bool pack_wino_bf3(void* dst, const float* src, int N, int K);            // [N][K][3][3] -> U = G g G^T, hi | lo, MFMA B-operand order
 
 int launch_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                      int batch, int n_heads, int d_head, int lq, int lk, hipStream_t stream);

@@ -1126,6 +1126,12 @@ int pf_pack_upfold_weight_bf16x3(const float* w, int n, int k, void* dst) {
   PF_REQUIRE(pack_upfold_bf3(dst, w, n, k, (n + 63) / 64 * 64), X3_RANGE_MSG, "pf_pack_upfold_weight_bf16x3");
   return PF_OK;
 }
+size_t pf_wino_weight_bytes(int n, int k) { return (n > 0 && k > 0) ? (size_t)16 * k * n * 4 : 0; }
+int pf_pack_wino_weight_bf16x3(const float* w, int n, int k, void* dst) {
+  PF_REQUIRE(w && dst && n > 0 && k > 0 && n % 64 == 0 && k % 16 == 0, "pack_wino: n must be a multiple of 64 and k of 16 (n=%d k=%d)", n, k);
+  PF_REQUIRE(pack_wino_bf3(dst, w, n, k), X3_RANGE_MSG, "pf_pack_wino_weight_bf16x3");
+  return PF_OK;
+}
 int pf_prmat2c_durations(const float* prmat2c, int n, int steps, int custom_round, int32_t* dur, void* stream) {
   return launch_prmat2c_durations(prmat2c, n, steps, custom_round, dur, (hipStream_t)stream);
 }

@@ -1,0 +1,89 @@
+"""The fused Winograd F(2x2, 3x3) form of the ResBlock convolution (csrc/conv_wino.hip; -m gpu): pf_conv2d with pf_conv_args.wino against
+torch's F.conv2d(F.silu(F.group_norm(x))) + bias + per-sample bias + residual (ref: stable_diffusion/model/unet.py:262-318), against the
+direct form of the same launch, its GroupNorm tile statistics against sums over the stored output, and bit-reproducibility."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from polyffusion_amd import _lib  # noqa: E402
+from test_gpu_ops import dev, gn_scale_shift, nhwc, rnd, run_conv  # noqa: E402
+from test_gpu_bf16x3 import pack3  # noqa: E402
+
+TOL_OP = 1e-4   # on O(1) outputs; the direct split form sits at ~3e-5, the transforms amplify operand rounding ~1.5x
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.require_gpu()
+    return _lib.load()
+
+
+def pack_wino(lib, w):
+    n, k = w.shape[0], w.shape[1]
+    dst = torch.zeros(lib.pf_wino_weight_bytes(n, k), dtype=torch.uint8)
+    _lib.check(lib.pf_pack_wino_weight_bf16x3(w.contiguous().data_ptr(), n, k, dst.data_ptr()))
+    return dst.cuda()
+
+
+SHAPES = [(2, 32, 32, 64, 0, 64), (1, 128, 128, 64, 0, 64), (2, 64, 64, 128, 64, 128), (1, 16, 16, 32, 32, 64), (3, 16, 48, 64, 0, 128),
+          (1, 64, 64, 256, 128, 128)]
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,cout", SHAPES)
+def test_wino_conv_gn_silu_vs_torch(lib, B, H, W, c0, c1, cout):
+    cin = c0 + c1
+    x = rnd((B, cin, H, W), 1) * 1.5 + 0.3
+    w, bias = rnd((cout, cin, 3, 3), 2, (1.0 / (cin * 9)) ** 0.5), rnd((cout,), 3, 0.1)
+    gamma, beta = 1 + 0.1 * rnd((cin,), 4), 0.1 * rnd((cin,), 5)
+    sb, res = rnd((B, cout), 6), rnd((B, cout, H, W), 7)
+    ref = F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-5)), w, bias, padding=1) + sb[:, :, None, None] + res
+    x0 = dev(nhwc(x[:, :c0]))
+    x1 = dev(nhwc(x[:, c0:])) if c1 else None
+    sc, sh = gn_scale_shift(lib, x0, x1, dev(gamma), dev(beta), 1e-5)
+    kw = dict(x0=x0, c0=c0, x1=x1, c1=c1, batch=B, hin=H, win=W, ks=3, stride=1, ups=0, w=pack3(lib, w), n=cout, prologue=1, sc=sc, sh=sh,
+              bias=dev(bias), sbias=dev(sb), ld_sbias=cout, res=dev(nhwc(res)), ld_res=cout, ld_out=cout, precision=1)
+    a = _lib.ConvArgs()
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+    ww = pack_wino(lib, w)
+    a.w_wino, a.wino = ww.data_ptr(), 1
+    nt = lib.pf_conv_stats_tiles(C.byref(a))
+    assert nt == (H // 16) * (W // 16)
+    stats = torch.full((B, nt, cout, 2), float("nan"), device="cuda")
+    out = torch.full((B, H, W, cout), float("nan"), device="cuda")
+    run_conv(lib, out=out, stats_out=stats, w_wino=ww, wino=1, **kw)
+    err = (out.cpu() - nhwc(ref)).abs().max().item()
+    direct = torch.empty(B, H, W, cout, device="cuda")
+    run_conv(lib, out=direct, **kw)
+    err_d = (direct.cpu() - nhwc(ref)).abs().max().item()
+    print(f"wino {B}x{H}x{W} {c0}+{c1}->{cout}: max-abs-diff vs torch {err:.2e} (direct form {err_d:.2e})")
+    assert err < TOL_OP, err
+    # tile statistics = per-channel (sum, sum of squares) of the stored outputs over each 16x16-pixel tile
+    o = out.view(B, H // 16, 16, W // 16, 16, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, nt, 256, cout).double()
+    want = torch.stack([o.sum(2), (o * o).sum(2)], dim=-1)
+    rel = ((stats.double() - want).abs() / (want.abs() + 1.0)).max().item()
+    assert rel < 1e-5, rel
+    # bit-reproducible
+    out2 = torch.empty_like(out)
+    run_conv(lib, out=out2, w_wino=ww, wino=1, **kw)
+    assert torch.equal(out.view(torch.int32), out2.view(torch.int32))
+
+
+def test_wino_falls_back_when_not_eligible(lib):
+    """hin not a multiple of 16: the launch runs the direct form on `w` (and says so through the statistics tile count)."""
+    B, H, W, c, cout = 1, 24, 40, 64, 64
+    x = rnd((B, c, H, W), 11)
+    w = rnd((cout, c, 3, 3), 12, (1.0 / (c * 9)) ** 0.5)
+    gamma, beta = 1 + 0.1 * rnd((c,), 13), 0.1 * rnd((c,), 14)
+    ref = F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-5)), w, None, padding=1)
+    x0 = dev(nhwc(x))
+    sc, sh = gn_scale_shift(lib, x0, None, dev(gamma), dev(beta), 1e-5)
+    out = torch.empty(B, H, W, cout, device="cuda")
+    ww = pack_wino(lib, w)
+    run_conv(lib, x0=x0, c0=c, batch=B, hin=H, win=W, ks=3, stride=1, ups=0, w=pack3(lib, w), n=cout, prologue=1, sc=sc, sh=sh, out=out,
+             ld_out=cout, precision=1, w_wino=ww, wino=1)
+    assert (out.cpu() - nhwc(ref)).abs().max() < 3e-4
