@@ -25,11 +25,115 @@ namespace pf {
 
 typedef x3_t x3x4 __attribute__((ext_vector_type(4)));
 
+#ifdef PF_TRACE
+__device__ unsigned long long g_wtrace[3 * 256];
+#define WTR() do { if (trace_on && tslot < 255) { g_wtrace[tbase + tslot++] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define WTR_DECL() const bool trace_on = (threadIdx.x == 0) && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1); \
+                   const int tbase = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 512 : 256); int tslot = 0; (void)tbase
+#else
+#define WTR() do {} while (0)
+#define WTR_DECL() do {} while (0)
+#endif
+
 // halo image in the LDS: [18 rows][18 pixels][32 channels + 4 pad] fp32, row pitch padded by 8 floats; the 16-byte channel piece of a pixel
 // sits at position (piece ^ ((row >> 1) & 1)).  With these three choices the b128 reads of the A-operand layout (lane = tile, stride two
 // pixels / two rows) are bank-conflict free in every hardware lane group (tools/micro/wino_banks.py).
 constexpr int WPP = 36, WRP = 18 * WPP + 8, WHALO = 18 * WRP;
 constexpr int WINO_LDS = 4 * 2 * 4 * 16 * 64 * 4;   // the S exchange (131072 B) is the largest user; halo images: 47232 B each
+
+// ---- output transform + epilogue (shared by the kernel forms).  acc[j][h][nb]: this wave's row of the transform domain.
+__device__ __forceinline__ void wino_epilogue(const ConvP& p, f32x16 (&acc)[4][2][2], unsigned char* smem_all, int b, int oy0, int ox0, int n0,
+                                              int ty_t, int tx_t, int wave, int lane, int tid, bool trace_on = false, int tbase = 0, int tslot = 0) {
+  (void)trace_on; (void)tbase; (void)tslot;
+  // wave w finishes block (h = w >> 1, nb = w & 1).  Registers 4u..4u+3 of a block = tiles (tyl = u, txl = 4 * (lane >> 5) + 0..3), channel
+  // lane & 31; after the lane-quad transpose a lane owns tile txl = 4 * (lane >> 5) + (lane & 3) and the four channels cq..cq+3.
+  const int fh = wave >> 1, fnb = wave & 1;
+  const int j4 = lane & 3, cq = (lane & 31) & ~3;
+  const int n = n0 + fnb * 32 + cq;
+  auto pix = [&](int u, int pp, int q) { return (int)out_pixel(p, b, oy0 + 2 * (4 * fh + u) + pp, ox0 + 2 * (4 * (lane >> 5) + j4) + q); };
+  // the residual rows and biases are requested before anything else: their latency hides behind the exchange
+  f32x4 rr[4][2][2];
+  if (p.res) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) rr[u][pp][q] = *reinterpret_cast<const f32x4*>(p.res + (size_t)pix(u, pp, q) * p.ld_res + n);
+  }
+  const float* sb = sbias_row(p, b);
+  f32x4 cb4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) cb4 += *reinterpret_cast<const f32x4*>(p.bias + n);
+  if (sb) cb4 += *reinterpret_cast<const f32x4*>(sb + n);
+  if (p.bias2) cb4 += *reinterpret_cast<const f32x4*>(p.bias2 + n);
+  // ---- output transform, column half in registers: S[q] = M[i][.] A  (A^T = [1 1 1 0; 0 1 -1 -1]), then the exchange
+  __syncthreads();            // the halo image is dead
+  float* X = reinterpret_cast<float*>(smem_all);   // [(i*2+q)*4 + blk][r/4][lane][4]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int blk = h * 2 + nb;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 s0, s1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = rq * 4 + e;
+          s0[e] = acc[0][h][nb][r] + acc[1][h][nb][r] + acc[2][h][nb][r];
+          s1[e] = acc[1][h][nb][r] - acc[2][h][nb][r] - acc[3][h][nb][r];
+        }
+        *reinterpret_cast<f32x4*>(X + ((((wave * 2 + 0) * 4 + blk) * 4 + rq) * 64 + lane) * 4) = s0;
+        *reinterpret_cast<f32x4*>(X + ((((wave * 2 + 1) * 4 + blk) * 4 + rq) * 64 + lane) * 4) = s1;
+      }
+    }
+  WTR();
+  __syncthreads();
+  WTR();
+  // Y[0][q] = S0 + S1 + S2, Y[1][q] = S1 - S2 - S3
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      f32x4 sv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sv[i] = *reinterpret_cast<const f32x4*>(X + ((((i * 2 + q) * 4 + wave) * 4 + u) * 64 + lane) * 4);
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp) {
+        f32x4 v = pp == 0 ? sv[0] + sv[1] + sv[2] : sv[1] - sv[2] - sv[3];
+        quad_transpose(v, lane);
+        v = PF_X3_UNSCALE(v) + cb4;
+        if (p.res) v += rr[u][pp][q];
+        *reinterpret_cast<f32x4*>(p.out + (size_t)pix(u, pp, q) * p.ld_out + n) = v;
+        s1 += v; s2 += v * v;
+      }
+    }
+  WTR();
+  if (p.stats) {   // workgroup-uniform
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = quad_sum(s1[e]), c = quad_sum(s2[e]);
+      a += __shfl_xor(a, 32); c += __shfl_xor(c, 32);
+      s1[e] = a; s2[e] = c;
+    }
+    __syncthreads();          // the exchange area is dead
+    float* red = reinterpret_cast<float*>(smem_all);   // [h][64 channels][2]
+    if (lane < 32 && j4 == 0) {
+      float* pr = red + (fh * 64 + fnb * 32 + cq) * 2;
+      *reinterpret_cast<f32x4*>(pr) = f32x4{s1[0], s2[0], s1[1], s2[1]};
+      *reinterpret_cast<f32x4*>(pr + 4) = f32x4{s1[2], s2[2], s1[3], s2[3]};
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int tile = ty_t * p.tiles_x + tx_t;
+      float* dst = p.stats + (((size_t)b * (p.tiles_x * p.tiles_y) + tile) * p.N + n0 + tid) * 2;
+      dst[0] = red[tid * 2] + red[(64 + tid) * 2];
+      dst[1] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
+    }
+  }
+  WTR();
+}
 
 template <int DUMMY>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(ConvP p) {
@@ -160,96 +264,318 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(ConvP p) {
     }
   }
 
-  // ---- output transform, column half in registers: S[q] = M[i][.] A  (A^T = [1 1 1 0; 0 1 -1 -1]), then the exchange
-  __syncthreads();            // the halo image is dead
-  float* X = reinterpret_cast<float*>(smem_all);   // [(i*2+q)*4 + blk][r/4][lane][4]
+  wino_epilogue(p, acc, smem_all, b, oy0, ox0, n0, ty_t, tx_t, wave, lane, tid);
+}
+
+// ---- split of four fp32 values into hi | lo pieces.  lo = v - float(hi) is formed by a two-element dot product on the packed hi pair
+// (v_dot2c_f32_bf16 / _f16 with the constant (-1, 0) or (0, -1) and v as the accumulator): no unpacking of hi - 8 instructions per four
+// elements instead of 10.  v - hi is exactly representable, so the result is the one of the subtract form.
+typedef x3_t x3x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (the two constants come from registers the compiler cannot see through: folded into the instruction they would become an INLINE
+// constant, and what "-1.0" means for a packed 16-bit pair operand of this instruction is not something to rely on)
+struct SplitK { unsigned c0, c1; };
+__device__ __forceinline__ SplitK split_consts() {
+#ifdef PF_X3_F16
+  SplitK k{0x0000BC00u, 0xBC000000u};      // (-1, 0), (0, -1) as fp16 pairs
+#else
+  SplitK k{0x0000BF80u, 0xBF800000u};      // ... as bf16 pairs
+#endif
+  asm volatile("" : "+s"(k.c0), "+s"(k.c1));
+  return k;
+}
+__device__ __forceinline__ float x3_sub_hi(x3x2 hp, unsigned c, float v) {
+#ifdef PF_X3_F16
+  return __builtin_amdgcn_fdot2(hp, __builtin_bit_cast(x3x2, c), v, false);
+#else
+  return __builtin_amdgcn_fdot2_f32_bf16(hp, __builtin_bit_cast(x3x2, c), v, false);
+#endif
+}
+__device__ __forceinline__ void split4(f32x4 v, x3x4& hi, x3x4& lo, SplitK k) {
+  const x3x2 h01 = __builtin_convertvector(f32x2{v[0], v[1]}, x3x2), h23 = __builtin_convertvector(f32x2{v[2], v[3]}, x3x2);
+  const float l0 = x3_sub_hi(h01, k.c0, v[0]), l1 = x3_sub_hi(h01, k.c1, v[1]), l2 = x3_sub_hi(h23, k.c0, v[2]), l3 = x3_sub_hi(h23, k.c1, v[3]);
+  const x3x2 q01 = __builtin_convertvector(f32x2{l0, l1}, x3x2), q23 = __builtin_convertvector(f32x2{l2, l3}, x3x2);
+  hi = __builtin_shufflevector(h01, h23, 0, 1, 2, 3);
+  lo = __builtin_shufflevector(q01, q23, 0, 1, 2, 3);
+}
+
+// a pointer every lane holds the same value of, moved to scalar registers (a buffer resource built from a pointer the compiler cannot PROVE
+// uniform is legalised with a read-first-lane loop around every load that uses it)
+template <class T>
+__device__ __forceinline__ const T* uniform_ptr(const T* q) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
+}
+
+// ---- the pipelined form.  A "step" is one (16-channel half s, tile half h) of a 32-channel chunk: 24 MFMAs (4 columns j of the transform
+// domain x 2 channel blocks x {lo.hi, hi.lo, hi.hi}), in column order so that a column's weight fragments die after its 6 MFMAs of the h = 1
+// step and are re-loaded right there for the next 16 channels - one whole step before their next use, 64 registers of weights in all.
+// Everything else runs in the shadow of those MFMAs, dealt out in small items between them (an in-order wave hides what it issues while
+// the matrix pipe is busy): the LDS reads, transform and split of the NEXT step's input fragments (two register sets), the normalise +
+// SiLU + LDS write of the next chunk's halo image (two images; three pixels per step, their global loads issued two steps earlier), the
+// weight re-loads.  One workgroup barrier per chunk.  All loads are ordinary loads: the compiler's wait counts are exact.
+template <int DUMMY>
+__global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  WTR_DECL();
+  WTR();
+  float* H0 = reinterpret_cast<float*>(smem_all);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = row i of the transform domain
+
+  int lid;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  int mt = fdiv(lid, p.d_nt);
+  const int nti = lid - mt * p.nt;
+  int t = fdiv(mt, p.d_tx);
+  const int tx_t = mt - t * p.tiles_x; mt = t;
+  const int b = fdiv(mt, p.d_ty);
+  const int ty_t = mt - b * p.tiles_y;
+  const int n0 = nti * 64, oy0 = ty_t * 16, ox0 = tx_t * 16;
+  conv_shared_x1(p, b);
+  const int cin = p.c0 + p.c1, nchunk = cin / 32, KK = cin / 16;
+
+  if (p.gn_s0) gn_fused_prologue<256>(p, b, tid, p.Hin * p.Win, reinterpret_cast<double*>(smem_all));
+
+  // ---- halo staging: piece = (pixel, 4-channel group); a thread keeps one channel group (256 % 8 == 0) and 11 pixels.
+  // gp[i] = (pixel index + 1, 0 = outside the image) | (LDS float offset / 4) << 20, kept in the LDS behind the two halo images
+  // ([piece][thread]: the registers are needed elsewhere) and read back one item ahead of its use
+  const int sub = tid & 7;
+  int* gpL = reinterpret_cast<int*>(H0 + 2 * WHALO) + tid;
+  int gpr[11];                                   // register copies for the prologue's loads
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int it = 0; it < 11; ++it) {
+    const int pix = min((tid >> 3) + 32 * it, 323);           // (the last round's surplus threads repeat pixel 323: same value, same place)
+    const int row = pix / 18, col = pix - row * 18;
+    const int iy = oy0 - 1 + row, ix = ox0 - 1 + col;
+    const int gpix = (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) ? (b * p.Hin + iy) * p.Win + ix + 1 : 0;
+    const int lo4 = (row * WRP + col * WPP) / 4 + (sub ^ ((row >> 1) & 1));
+    gpr[it] = gpix | (lo4 << 20);
+    gpL[it * 256] = gpr[it];
+  }
+  const __amdgpu_buffer_rsrc_t rsSc = dma_resource(uniform_ptr(p.sc + (size_t)b * cin)), rsSh = dma_resource(uniform_ptr(p.sh + (size_t)b * cin));
+  // the sample's GroupNorm scale / shift rows, in the LDS behind the piece words: a step reads its eight values right before its staging
+  // items and lets them go afterwards (eight registers that the fragment items need in the first two thirds of a step)
+  float* scL = reinterpret_cast<float*>(gpL - tid + 11 * 256);
+  float* shL = scL + cin;
+  const float* px0 = uniform_ptr(p.x0);
+  const float* px1 = uniform_ptr(p.x1);
+  f32x4 ra[11], vsc, vsh;
+  auto scRead = [&](int ct) {
+    vsc = *reinterpret_cast<const f32x4*>(scL + ct * 32 + sub * 4);
+    vsh = *reinterpret_cast<const f32x4*>(shL + ct * 32 + sub * 4);
+  };
+  int gq = 0, gst = 0;                            // piece words read one item ahead of their use (an LDS read right before its use stalls the wave)
+  auto gpRead = [&](int pi) { gq = gpL[pi * 256]; };
+  auto haloFetch = [&](int ct, int gpv) -> f32x4 {          // global load of the piece with word gpv of chunk ct
+    const int cg = ct * 32;
+    const bool first = cg < p.c0;                // wave-uniform: the source tensor of this chunk
+    const __amdgpu_buffer_rsrc_t rs = dma_resource(first ? px0 : px1);
+    const int cs4 = (first ? p.c0 : p.c1) * 4, co4 = (first ? cg : cg - p.c0) * 4;
+    const int gpix = (gpv & 0xFFFFF) - 1;
+    const int vo = gpix < 0 ? (int)0x80000000u : (int)__umul24(gpix, cs4) + sub * 16;     // outside: an offset >= the resource's size reads as zero, no access
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, co4, 0));
+  };
+  auto haloLoad = [&](int pi, int ct, int gpv) { ra[pi] = haloFetch(ct, gpv); };
+  auto stageWhole = [&](f32x4 r, f32x4 sc4, f32x4 sh4, int gpv, float* Ht) {     // prologue: a whole piece at once
+    r = r * sc4 + sh4;
+    r[0] = silu_f(r[0]); r[1] = silu_f(r[1]); r[2] = silu_f(r[2]); r[3] = silu_f(r[3]);
+    const f32x4 v = (gpv & 0xFFFFF) ? r : f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(Ht + (((unsigned)gpv >> 20) << 2)) = v;
+  };
+  auto scLoad = [&](int ct) {
+    vsc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsSc, sub * 16, ct * 128, 0));
+    vsh = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsSh, sub * 16, ct * 128, 0));
+  };
+  auto stageA = [&](int pi) {                    // first half of a piece: normalise, SiLU of two elements
+    gst = gpL[pi * 256];
+    ra[pi] = ra[pi] * vsc + vsh;
+    ra[pi][0] = silu_f(ra[pi][0]); ra[pi][1] = silu_f(ra[pi][1]);
+  };
+  auto stageB = [&](int pi, float* Ht) {         // second half + the LDS write (zero padding applies to the ACTIVATED tensor)
+    ra[pi][2] = silu_f(ra[pi][2]); ra[pi][3] = silu_f(ra[pi][3]);
+    const int gpv = gst;
+    const f32x4 v = (gpv & 0xFFFFF) ? ra[pi] : f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(Ht + (((unsigned)gpv >> 20) << 2)) = v;
+  };
+
+  // ---- A-operand side: lane = (tile m = lane & 31, channel group g = lane >> 5); B^T row of this wave: t = x + sigma * y
+  const int m = lane & 31, g = lane >> 5, tyl = m >> 3, txl = m & 7;
+  const int ax = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+  const int ay = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+  const float sigma = wave == 1 ? 1.f : -1.f;
+  // float offsets of this lane's first pixel in the x / y row of tile half 0 for channel half 0, with the piece swizzle folded in (it does
+  // not depend on the tile half: 4 h is even).  The pixel base is a multiple of 8 floats, so channel half 1 - the neighbouring 16-byte
+  // piece - is the same offset ^ 4 (formed where it is used: two registers instead of four); everything else of a fragment read's
+  // address - pixel, 16-channel step, tile half - is a compile-time constant: the instruction's offset field.
+  int ox_, oy_;
+  {
+    const int rx = 2 * tyl + ax, ry = 2 * tyl + ay;
+    ox_ = rx * WRP + (2 * txl) * WPP + (((2 * g) ^ ((rx >> 1) & 1)) << 2);
+    oy_ = ry * WRP + (2 * txl) * WPP + (((2 * g) ^ ((ry >> 1) & 1)) << 2);
+    asm volatile("" : "+v"(ox_), "+v"(oy_));   // opaque (the compiler otherwise keeps - and spills - their many parts)
+  }
+  const SplitK spk = split_consts();
+  f32x4 rwx[2], rwy[2], tt[4];
+  x3x4 fh_[2][4][2], fl_[2][4][2];              // input fragments [set][j][channel half]: hi | lo
+  auto fragRead = [&](const float* Hn, int s, int h, int e, int b2) {     // pixels 2 * b2, 2 * b2 + 1 of the two rows
+    int ex = ox_, ey = oy_;
+    if (e) { asm volatile("v_xor_b32 %0, 4, %1" : "=v"(ex) : "v"(ox_)); asm volatile("v_xor_b32 %0, 4, %1" : "=v"(ey) : "v"(oy_)); }   // (volatile: not hoisted out of the loop)
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      rwx[bb] = *reinterpret_cast<const f32x4*>(Hn + ex + ((2 * b2 + bb) * WPP + s * 16 + h * 8 * WRP));
+      rwy[bb] = *reinterpret_cast<const f32x4*>(Hn + ey + ((2 * b2 + bb) * WPP + s * 16 + h * 8 * WRP));
+    }
+  };
+  auto fragT = [&](int b2) {
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) tt[2 * b2 + bb] = rwx[bb] + sigma * rwy[bb];
+  };
+  auto fragV = [&](int set, int j, int e) {
+    const f32x4 v = j == 0 ? tt[0] - tt[2] : (j == 1 ? tt[1] + tt[2] : (j == 2 ? tt[2] - tt[1] : tt[1] - tt[3]));
+    split4(v, fh_[set][j][e], fl_[set][j][e], spk);
+  };
+
+  // weights: [i][kk][ntile][j][nb][plane][lane][8]: 16 KB per (i, kk, ntile)
+  const __amdgpu_buffer_rsrc_t rsW = dma_resource(uniform_ptr(static_cast<const x3_t*>(p.w) + ((size_t)wave * KK * p.nt + nti) * 8192));
+  const int wstep = p.nt * 16384;                // bytes between consecutive 16-channel steps
+  x3x8 bh[4][2], bl[4][2];
+  auto wLoad = [&](int j, int kk) {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      const int blk = h * 2 + nb;
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        f32x4 s0, s1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = rq * 4 + e;
-          s0[e] = acc[0][h][nb][r] + acc[1][h][nb][r] + acc[2][h][nb][r];
-          s1[e] = acc[1][h][nb][r] - acc[2][h][nb][r] - acc[3][h][nb][r];
-        }
-        *reinterpret_cast<f32x4*>(X + ((((wave * 2 + 0) * 4 + blk) * 4 + rq) * 64 + lane) * 4) = s0;
-        *reinterpret_cast<f32x4*>(X + ((((wave * 2 + 1) * 4 + blk) * 4 + rq) * 64 + lane) * 4) = s1;
-      }
+      bh[j][nb] = __builtin_bit_cast(x3x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, lane * 16, kk * wstep + ((j * 2 + nb) * 2 + 0) * 1024, 0));
+      bl[j][nb] = __builtin_bit_cast(x3x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, lane * 16, kk * wstep + ((j * 2 + nb) * 2 + 1) * 1024, 0));
     }
-  __syncthreads();
-  // wave w finishes block (h = w >> 1, nb = w & 1): Y[0][q] = S0 + S1 + S2, Y[1][q] = S1 - S2 - S3
-  const int fh = wave >> 1, fnb = wave & 1;
-  f32x4 yv[2][2][4];          // [p][q][register quad]
+  };
+
+  auto wLoad1 = [&](int j, int nb, bool lo, int kk) {
+    if (lo) bl[j][nb] = __builtin_bit_cast(x3x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, lane * 16, kk * wstep + ((j * 2 + nb) * 2 + 1) * 1024, 0));
+    else bh[j][nb] = __builtin_bit_cast(x3x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, lane * 16, kk * wstep + ((j * 2 + nb) * 2 + 0) * 1024, 0));
+  };
+  f32x16 acc[4][2][2];
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+  // ---- prologue: every global load the first steps depend on goes out first (weights of the first 16 channels, the rows of scale /
+  // shift, the halo of chunk 0 and the first three pixels of chunk 1); the accumulators are cleared while they fly; then the image of
+  // chunk 0, the three pixels, the loads of the next six, the barrier, and the fragments of step 0
+  {
+    const int c1 = min(1, nchunk - 1);
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+    for (int j = 0; j < 4; ++j) wLoad(j, 0);
+    scLoad(0);
+    const f32x4 vsc0 = vsc, vsh0 = vsh;
+    scLoad(c1);
+    float tsc[4], tsh[4];                        // this thread's share of the rows (cin <= 1024)
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      f32x4 sv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sv[i] = *reinterpret_cast<const f32x4*>(X + ((((i * 2 + q) * 4 + wave) * 4 + rq) * 64 + lane) * 4);
-      yv[0][q][rq] = sv[0] + sv[1] + sv[2];
-      yv[1][q][rq] = sv[1] - sv[2] - sv[3];
+    for (int i = 0; i < 4; ++i) {
+      const int c = min(tid + 256 * i, cin - 1);
+      tsc[i] = p.sc[(size_t)b * cin + c]; tsh[i] = p.sh[(size_t)b * cin + c];
     }
-  // registers 4u..4u+3 of a block = tiles (tyl = u, txl = 4 * (lane >> 5) + 0..3), channel lane & 31; after the lane-quad transpose a
-  // lane owns tile txl = 4 * (lane >> 5) + (lane & 3) and the four channels cq..cq+3
-  const int j4 = lane & 3, cq = (lane & 31) & ~3;
-  const int n = n0 + fnb * 32 + cq;
-  const float* sb = sbias_row(p, b);
-  f32x4 cb4 = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) cb4 += *reinterpret_cast<const f32x4*>(p.bias + n);
-  if (sb) cb4 += *reinterpret_cast<const f32x4*>(sb + n);
-  if (p.bias2) cb4 += *reinterpret_cast<const f32x4*>(p.bias2 + n);
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    size_t mo[2][2];
-    f32x4 rr[2][2];
+    for (int pi = 0; pi < 11; ++pi) haloLoad(pi, 0, gpr[pi]);
+    f32x4 rb[3];
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp)
+    for (int pi = 0; pi < 3; ++pi) rb[pi] = haloFetch(c1, gpr[pi]);
+    WTR();
+    SB();
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        mo[pp][q] = out_pixel(p, b, oy0 + 2 * (4 * fh + u) + pp, ox0 + 2 * (4 * (lane >> 5) + j4) + q);
-        if (p.res) rr[pp][q] = *reinterpret_cast<const f32x4*>(p.res + mo[pp][q] * p.ld_res + n);
-      }
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        f32x4 v = yv[pp][q][u];
-        quad_transpose(v, lane);
-        v = PF_X3_UNSCALE(v) + cb4;
-        if (p.res) v += rr[pp][q];
-        *reinterpret_cast<f32x4*>(p.out + mo[pp][q] * p.ld_out + n) = v;
-        s1 += v; s2 += v * v;
-      }
-  }
-  if (p.stats) {   // workgroup-uniform
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float a = quad_sum(s1[e]), c = quad_sum(s2[e]);
-      a += __shfl_xor(a, 32); c += __shfl_xor(c, 32);
-      s1[e] = a; s2[e] = c;
-    }
-    __syncthreads();          // the exchange area is dead
-    float* red = reinterpret_cast<float*>(smem_all);   // [h][64 channels][2]
-    if (lane < 32 && j4 == 0) {
-      float* pr = red + (fh * 64 + fnb * 32 + cq) * 2;
-      *reinterpret_cast<f32x4*>(pr) = f32x4{s1[0], s2[0], s1[1], s2[1]};
-      *reinterpret_cast<f32x4*>(pr + 4) = f32x4{s1[2], s2[2], s1[3], s2[3]};
-    }
+          for (int r = 0; r < 16; ++r) acc[j][h][nb][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (tid + 256 * i < cin) { scL[tid + 256 * i] = tsc[i]; shL[tid + 256 * i] = tsh[i]; }
+    SB();
+#pragma unroll
+    for (int pi = 0; pi < 11; ++pi) stageWhole(ra[pi], vsc0, vsh0, gpr[pi], H0);
+    WTR();
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) stageWhole(rb[pi], vsc, vsh, gpr[pi], H0 + WHALO);
+#pragma unroll
+    for (int pi = 3; pi < 9; ++pi) haloLoad(pi, c1, gpr[pi]);
+    WTR();
     __syncthreads();
-    if (tid < 64) {
-      const int tile = ty_t * p.tiles_x + tx_t;
-      float* dst = p.stats + (((size_t)b * (p.tiles_x * p.tiles_y) + tile) * p.N + n0 + tid) * 2;
-      dst[0] = red[tid * 2] + red[(64 + tid) * 2];
-      dst[1] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
+    WTR();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      fragRead(H0, 0, 0, e, 0); fragT(0); fragRead(H0, 0, 0, e, 1); fragT(1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fragV(0, j, e);
     }
   }
+
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const int c1 = min(chunk + 1, nchunk - 1), c2 = min(chunk + 2, nchunk - 1);
+    float* Hcur = H0 + (chunk & 1) * WHALO;
+    float* Hnxt = H0 + ((chunk + 1) & 1) * WHALO;
+    static_for<0, 4>([&](auto qc) {
+      constexpr int QS = decltype(qc)::value, s = QS >> 1, h = QS & 1;
+      constexpr int QN = (QS + 1) & 3, sn = QN >> 1, hn = QN & 1;       // the step whose fragments are produced now, into set hn
+      const float* Hn = QS == 3 ? Hnxt : Hcur;
+      float* Ht = QS == 3 ? Hcur : Hnxt;                                // image written by this step's staging items
+      // staging pieces of this step (first, count) and the pieces whose global loads it issues (first, count, chunk)
+      constexpr int sp0 = QS == 3 ? 0 : 3 * QS + 3, spn = QS == 2 ? 2 : 3;
+      constexpr int lp0 = QS == 0 ? 9 : 3 * (QS - 1), lpn = QS == 0 ? 2 : 3;
+      const int lct = QS == 0 ? c1 : c2;
+      WTR();
+      if constexpr (QS == 3) {
+        // all staging writes of the next image are done and visible, every wave has read the last fragments of the current one
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      SB();
+      static_for<0, 24>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, j = k / 6, kind = (k % 6) >> 1, nb = k & 1;
+        const x3x8 ah = __builtin_shufflevector(fh_[h][j][0], fh_[h][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        const x3x8 al = __builtin_shufflevector(fl_[h][j][0], fl_[h][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (kind == 0) acc[j][h][nb] = x3_mfma_32x32x16(al, bh[j][nb], acc[j][h][nb], 0, 0, 0);
+        else if constexpr (kind == 1) acc[j][h][nb] = x3_mfma_32x32x16(ah, bl[j][nb], acc[j][h][nb], 0, 0, 0);
+        else acc[j][h][nb] = x3_mfma_32x32x16(ah, bh[j][nb], acc[j][h][nb], 0, 0, 0);
+        SB();
+        // ---- the item of this slot
+        // next step's fragments, channel half e = 0 in slots 0-7, e = 1 in slots 8-15: read two pixels of both rows, t, read the other two, t, V x 4
+        if constexpr (k == 0 || k == 8) fragRead(Hn, sn, hn, k / 8, 0);
+        if constexpr (k == 2 || k == 10) { fragT(0); fragRead(Hn, sn, hn, k / 8, 1); }
+        if constexpr (k == 4 || k == 12) { fragT(1); fragV(hn, 0, k / 8); }
+        if constexpr (k == 5 || k == 6 || k == 7) fragV(hn, k - 4, 0);
+        if constexpr (k == 13 || k == 14 || k == 15) fragV(hn, k - 12, 1);
+        if constexpr (k >= 16 && k < 16 + 2 * spn) {
+          constexpr int pi = sp0 + (k - 16) / 2;
+          if constexpr (((k - 16) & 1) == 0) stageA(pi); else stageB(pi, Ht);
+        }
+        if constexpr (k == 3 || k == 9 || k == 11) {
+          constexpr int li = k == 3 ? 0 : (k == 9 ? 1 : 2);
+          if constexpr (li < lpn) haloLoad(lp0 + li, lct, gq);
+        }
+        if constexpr (k == 1 || k == 7 || k == 9) {            // piece word, one slot ahead of the load that needs it
+          constexpr int li = k == 1 ? 0 : (k == 7 ? 1 : 2);
+          if constexpr (li < lpn) gpRead(lp0 + li);
+        }
+        if constexpr (k == 15) scRead(QS == 3 ? c2 : c1);
+        // a weight fragment is re-loaded for the next 16 channels right after its last MFMA (lo plane: the hi.lo product, hi plane: hi.hi):
+        // one load per slot - four in a row stall the wave on the address unit the four waves share
+        if constexpr (h == 1 && (k % 6) >= 2) wLoad1(j, k & 1, (k % 6) < 4, s == 0 ? chunk * 2 + 1 : c1 * 2);
+        SB();
+      });
+    });
+  }
+#undef SB
+  WTR();
+#ifdef PF_TRACE
+  wino_epilogue(p, acc, smem_all, b, oy0, ox0, n0, ty_t, tx_t, wave, lane, tid, trace_on, tbase, tslot);
+#else
+  wino_epilogue(p, acc, smem_all, b, oy0, ox0, n0, ty_t, tx_t, wave, lane, tid);
+#endif
 }
 
 bool conv_wino_eligible(const pf_conv_args& a) {
@@ -276,14 +602,31 @@ int launch_conv_wino(const pf_conv_args& a, hipStream_t stream) {
   p.x1_bmod = a.x1_bmod;
   p.tiles_x = a.win / 16; p.tiles_y = a.hin / 16; p.nt = a.n / 64;
   conv_fill_divs(p);
-  auto kern = conv_wino_kernel<0>;
-  static std::atomic<uint64_t> attr_done{0};
-  if (int rc = set_max_lds_once(reinterpret_cast<const void*>(kern), WINO_LDS, attr_done)) return rc;
   const int grid = p.B * p.tiles_y * p.tiles_x * p.nt;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), WINO_LDS, stream, p);
+  if (a.wino == 2) {          // the plain (un-pipelined) form: development reference
+    auto kern = conv_wino_kernel<0>;
+    static std::atomic<uint64_t> attr_done{0};
+    if (int rc = set_max_lds_once(reinterpret_cast<const void*>(kern), WINO_LDS, attr_done)) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), WINO_LDS, stream, p);
+  } else {
+    auto kern = conv_wino_pipe_kernel<0>;
+    static std::atomic<uint64_t> attr_done{0};
+    if (int rc = set_max_lds_once(reinterpret_cast<const void*>(kern), WINO_LDS, attr_done)) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), WINO_LDS, stream, p);
+  }
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }
+
+#ifdef PF_TRACE
+extern "C" int pf_debug_wino_trace_read(unsigned long long* dst, int n) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wtrace), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+extern "C" int pf_debug_wino_trace_clear() {
+  static unsigned long long z[3 * 256];
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_wtrace), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // host: fp32 torch weight [N][K][3][3] -> U = G g G^T per (n, k), split into hi | lo pieces, in MFMA B-operand order
 // [i][K/16][N/64][j][nb][plane][lane = (k % 16 / 8) * 32 + n % 32][k % 8]   (N % 64 == 0, K % 16 == 0)
