@@ -41,95 +41,129 @@ __device__ unsigned long long g_wtrace[3 * 256];
 constexpr int WPP = 36, WRP = 18 * WPP + 8, WHALO = 18 * WRP;
 constexpr int WINO_LDS = 4 * 2 * 4 * 16 * 64 * 4;   // the S exchange (131072 B) is the largest user; halo images: 47232 B each
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory counter, i.e. waits for the residual rows
+// requested just before it
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// a pointer every lane holds the same value of, moved to scalar registers (a buffer resource built from a pointer the compiler cannot PROVE
+// uniform is legalised with a read-first-lane loop around every load that uses it)
+template <class T>
+__device__ __forceinline__ const T* uniform_ptr(const T* q) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
+}
+
+// buffer resource over a tensor that may be absent: a null pointer gives a resource of size zero - every load through it returns zeros,
+// no branch and no wait at the use
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_or_empty(const void* q) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q), 0, q ? 0x7fffffff : 0, 0x00020000);
+}
+// this sample's row of the per-sample bias, resolved with SCALAR loads (the row index table is read through the constant address space)
+__device__ __forceinline__ const float* sbias_row_scalar(const ConvP& p, int b) {
+  if (!p.sbias) return nullptr;
+  long long r = b;
+  if (p.sb_rows) {
+    typedef const long long __attribute__((address_space(4))) * cptr;
+    r = *((cptr)(unsigned long long)(p.sb_rows + b));
+    r = r < 0 ? 0 : (r >= p.sb_nrows ? p.sb_nrows - 1 : r);
+  }
+  return p.sbias + (size_t)r * p.ld_sbias;
+}
+
 // ---- output transform + epilogue (shared by the kernel forms).  acc[j][h][nb]: this wave's row of the transform domain.
 __device__ __forceinline__ void wino_epilogue(const ConvP& p, f32x16 (&acc)[4][2][2], unsigned char* smem_all, int b, int oy0, int ox0, int n0,
-                                              int ty_t, int tx_t, int wave, int lane, int tid, bool trace_on = false, int tbase = 0, int tslot = 0) {
+                                              int ty_t, int tx_t, int wave, int lane, int tid, const float* sb, bool trace_on = false, int tbase = 0, int tslot = 0) {
   (void)trace_on; (void)tbase; (void)tslot;
-  // wave w finishes block (h = w >> 1, nb = w & 1).  Registers 4u..4u+3 of a block = tiles (tyl = u, txl = 4 * (lane >> 5) + 0..3), channel
-  // lane & 31; after the lane-quad transpose a lane owns tile txl = 4 * (lane >> 5) + (lane & 3) and the four channels cq..cq+3.
+  // Wave w finishes block (h = w >> 1, nb = w & 1).  The exchange image is [slot = (i, q, block)][register r][lane] in single floats: the row of
+  // one (slot, r) holds the 32 channels of the tiles m = (r & 3) + 8 (r >> 2) + 4 g at lanes 32 g + channel, so a 16-byte READ at
+  // [r][32 g + 4 c] delivers four consecutive channels of one tile - the transposition the 16-byte global stores need happens in the LDS
+  // addressing instead of in 21 cross-lane instructions per quad.  Reader lane: c = lane & 7 (channel quad), tl = lane >> 3 (tile column);
+  // pass u = tile row: tile m = 8 u + tl  ->  r = (tl & 3) + 4 u, g = (tl >> 2) & 1.
   const int fh = wave >> 1, fnb = wave & 1;
-  const int j4 = lane & 3, cq = (lane & 31) & ~3;
-  const int n = n0 + fnb * 32 + cq;
-  auto pix = [&](int u, int pp, int q) { return (int)out_pixel(p, b, oy0 + 2 * (4 * fh + u) + pp, ox0 + 2 * (4 * (lane >> 5) + j4) + q); };
-  // the residual rows and biases are requested before anything else: their latency hides behind the exchange
+  const int c8 = lane & 7, tl = lane >> 3;
+  const int n = n0 + fnb * 32 + c8 * 4;
+  const int pix0 = (b * p.Hout + oy0 + 8 * fh) * p.Wout + ox0 + 2 * tl;
+  auto pix = [&](int u, int pp, int q) { return pix0 + (2 * u + pp) * p.Wout + q; };
+  // the residual rows and biases are requested before anything else (buffer loads: no 64-bit address arithmetic, absent tensors read as
+  // zero): their latency hides behind the exchange
+  const __amdgpu_buffer_rsrc_t rsRes = rsrc_or_empty(uniform_ptr(p.res)), rsOut = rsrc_or_empty(uniform_ptr(p.out));
   f32x4 rr[4][2][2];
-  if (p.res) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int pp = 0; pp < 2; ++pp)
+    for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) rr[u][pp][q] = *reinterpret_cast<const f32x4*>(p.res + (size_t)pix(u, pp, q) * p.ld_res + n);
-  }
-  const float* sb = sbias_row(p, b);
-  f32x4 cb4 = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) cb4 += *reinterpret_cast<const f32x4*>(p.bias + n);
-  if (sb) cb4 += *reinterpret_cast<const f32x4*>(sb + n);
-  if (p.bias2) cb4 += *reinterpret_cast<const f32x4*>(p.bias2 + n);
+      for (int q = 0; q < 2; ++q)
+        rr[u][pp][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsRes, (pix(u, pp, q) * p.ld_res + n) * 4, 0, 0));
+  const f32x4 cba = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_or_empty(uniform_ptr(p.bias)), n * 4, 0, 0));
+  const f32x4 cbb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_or_empty(uniform_ptr(sb)), n * 4, 0, 0));
+  const f32x4 cbc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_or_empty(uniform_ptr(p.bias2)), n * 4, 0, 0));
   // ---- output transform, column half in registers: S[q] = M[i][.] A  (A^T = [1 1 1 0; 0 1 -1 -1]), then the exchange
-  __syncthreads();            // the halo image is dead
-  float* X = reinterpret_cast<float*>(smem_all);   // [(i*2+q)*4 + blk][r/4][lane][4]
+  lds_barrier();              // the halo image is dead
+  float* X = reinterpret_cast<float*>(smem_all);
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const int blk = h * 2 + nb;
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        f32x4 s0, s1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = rq * 4 + e;
-          s0[e] = acc[0][h][nb][r] + acc[1][h][nb][r] + acc[2][h][nb][r];
-          s1[e] = acc[1][h][nb][r] - acc[2][h][nb][r] - acc[3][h][nb][r];
-        }
-        *reinterpret_cast<f32x4*>(X + ((((wave * 2 + 0) * 4 + blk) * 4 + rq) * 64 + lane) * 4) = s0;
-        *reinterpret_cast<f32x4*>(X + ((((wave * 2 + 1) * 4 + blk) * 4 + rq) * 64 + lane) * 4) = s1;
+      for (int r = 0; r < 16; ++r) {
+        const float s0 = acc[0][h][nb][r] + acc[1][h][nb][r] + acc[2][h][nb][r];
+        const float s1 = acc[1][h][nb][r] - acc[2][h][nb][r] - acc[3][h][nb][r];
+        X[((((wave * 2 + 0) * 4 + blk) * 16 + r) * 64) + lane] = s0;
+        X[((((wave * 2 + 1) * 4 + blk) * 16 + r) * 64) + lane] = s1;
       }
+      __builtin_amdgcn_sched_barrier(0);   // one block's 64 accumulators in vector registers at a time (all 256 at once spill)
     }
   WTR();
-  __syncthreads();
+  lds_barrier();
   WTR();
   // Y[0][q] = S0 + S1 + S2, Y[1][q] = S1 - S2 - S3
+  const f32x4 cb4 = cba + cbb + cbc;
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  const float* Xr = X + (tl & 3) * 64 + ((tl >> 2) & 1) * 32 + c8 * 4;
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       f32x4 sv[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sv[i] = *reinterpret_cast<const f32x4*>(X + ((((i * 2 + q) * 4 + wave) * 4 + u) * 64 + lane) * 4);
+      for (int i = 0; i < 4; ++i) sv[i] = *reinterpret_cast<const f32x4*>(Xr + ((((i * 2 + q) * 4 + wave) * 16 + 4 * u) * 64));
 #pragma unroll
       for (int pp = 0; pp < 2; ++pp) {
         f32x4 v = pp == 0 ? sv[0] + sv[1] + sv[2] : sv[1] - sv[2] - sv[3];
-        quad_transpose(v, lane);
-        v = PF_X3_UNSCALE(v) + cb4;
-        if (p.res) v += rr[u][pp][q];
-        *reinterpret_cast<f32x4*>(p.out + (size_t)pix(u, pp, q) * p.ld_out + n) = v;
+        v = PF_X3_UNSCALE(v) + cb4 + rr[u][pp][q];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsOut, (pix(u, pp, q) * p.ld_out + n) * 4, 0, 0);
         s1 += v; s2 += v * v;
       }
     }
   WTR();
   if (p.stats) {   // workgroup-uniform
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float a = quad_sum(s1[e]), c = quad_sum(s2[e]);
-      a += __shfl_xor(a, 32); c += __shfl_xor(c, 32);
-      s1[e] = a; s2[e] = c;
-    }
-    __syncthreads();          // the exchange area is dead
-    float* red = reinterpret_cast<float*>(smem_all);   // [h][64 channels][2]
-    if (lane < 32 && j4 == 0) {
-      float* pr = red + (fh * 64 + fnb * 32 + cq) * 2;
-      *reinterpret_cast<f32x4*>(pr) = f32x4{s1[0], s2[0], s1[1], s2[1]};
-      *reinterpret_cast<f32x4*>(pr + 4) = f32x4{s1[2], s2[2], s1[3], s2[3]};
-    }
-    __syncthreads();
+    // a lane summed its four channels over the 16 pixels of its tile column; the 16 partial sums of a channel (8 tile columns x 2 tile
+    // halves) meet in the LDS and are added in a fixed order by the channel's thread (cross-lane shuffles cost a round trip each here)
+    lds_barrier();            // the exchange area is dead
+    float* red = reinterpret_cast<float*>(smem_all);   // [wave][lane][8]
+    *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 8) = s1;
+    *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 8 + 4) = s2;
+    lds_barrier();
     if (tid < 64) {
+      const int nb = tid >> 5, cc = (tid & 31) >> 2, e = tid & 3;
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) {
+          const float* q = red + ((h * 2 + nb) * 64 + t8 * 8 + cc) * 8 + e;
+          a0 += q[0]; a1 += q[4];
+        }
       const int tile = ty_t * p.tiles_x + tx_t;
       float* dst = p.stats + (((size_t)b * (p.tiles_x * p.tiles_y) + tile) * p.N + n0 + tid) * 2;
-      dst[0] = red[tid * 2] + red[(64 + tid) * 2];
-      dst[1] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
+      dst[0] = a0; dst[1] = a1;
     }
   }
   WTR();
@@ -264,7 +298,29 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(ConvP p) {
     }
   }
 
-  wino_epilogue(p, acc, smem_all, b, oy0, ox0, n0, ty_t, tx_t, wave, lane, tid);
+  wino_epilogue(p, acc, smem_all, b, oy0, ox0, n0, ty_t, tx_t, wave, lane, tid, sbias_row(p, b));
+}
+
+// x * sigmoid(x) on a pair: the multiplies and the add as packed operations (two elements per instruction), one v_exp + one v_rcp per element
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_ silu2(f32x2_ v) {
+  f32x2_ t = v * -1.44269504088896340736f;
+  t[0] = __builtin_amdgcn_exp2f(t[0]); t[1] = __builtin_amdgcn_exp2f(t[1]);
+  t = t + 1.0f;
+  t[0] = __builtin_amdgcn_rcpf(t[0]); t[1] = __builtin_amdgcn_rcpf(t[1]);
+  return v * t;
+}
+
+// packed fp32 arithmetic the compiler does not form by itself here (it emits two scalar operations): a - b and a * b + c on pairs
+__device__ __forceinline__ f32x2_ pk_sub(f32x2_ a, f32x2_ b) { f32x2_ d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2_ pk_fma(f32x2_ a, f32x2_ b, f32x2_ c) { f32x2_ d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+  const f32x2_ l = pk_sub(f32x2_{a[0], a[1]}, f32x2_{b[0], b[1]}), h = pk_sub(f32x2_{a[2], a[3]}, f32x2_{b[2], b[3]});
+  return f32x4{l[0], l[1], h[0], h[1]};
+}
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x2_ s2, f32x4 c) {
+  const f32x2_ l = pk_fma(f32x2_{a[0], a[1]}, s2, f32x2_{c[0], c[1]}), h = pk_fma(f32x2_{a[2], a[3]}, s2, f32x2_{c[2], c[3]});
+  return f32x4{l[0], l[1], h[0], h[1]};
 }
 
 // ---- split of four fp32 values into hi | lo pieces.  lo = v - float(hi) is formed by a two-element dot product on the packed hi pair
@@ -299,15 +355,6 @@ __device__ __forceinline__ void split4(f32x4 v, x3x4& hi, x3x4& lo, SplitK k) {
   lo = __builtin_shufflevector(q01, q23, 0, 1, 2, 3);
 }
 
-// a pointer every lane holds the same value of, moved to scalar registers (a buffer resource built from a pointer the compiler cannot PROVE
-// uniform is legalised with a read-first-lane loop around every load that uses it)
-template <class T>
-__device__ __forceinline__ const T* uniform_ptr(const T* q) {
-  const unsigned long long v = reinterpret_cast<unsigned long long>(q);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
-}
-
 // ---- the pipelined form.  A "step" is one (16-channel half s, tile half h) of a 32-channel chunk: 24 MFMAs (4 columns j of the transform
 // domain x 2 channel blocks x {lo.hi, hi.lo, hi.hi}), in column order so that a column's weight fragments die after its 6 MFMAs of the h = 1
 // step and are re-loaded right there for the next 16 channels - one whole step before their next use, 64 registers of weights in all.
@@ -320,7 +367,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   WTR_DECL();
   WTR();
-  float* H0 = reinterpret_cast<float*>(smem_all);
+  // LDS: [4 KB dump | halo image 0 | 4 KB dump | halo image 1 | piece words | scale / shift rows]: a piece outside the image is written to its
+  // thread's slot of the dump region in front of the image it belongs to (its place in the image is zeroed once, below)
+  constexpr int WIMG = WHALO + 1024;
+  float* H0 = reinterpret_cast<float*>(smem_all) + 1024;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = row i of the transform domain
 
@@ -339,22 +389,31 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
   const int n0 = nti * 64, oy0 = ty_t * 16, ox0 = tx_t * 16;
   conv_shared_x1(p, b);
   const int cin = p.c0 + p.c1, nchunk = cin / 32, KK = cin / 16;
+  const float* sbp = sbias_row_scalar(p, b);     // (scalar registers: nothing to keep in a vector register across the loop)
 
   if (p.gn_s0) gn_fused_prologue<256>(p, b, tid, p.Hin * p.Win, reinterpret_cast<double*>(smem_all));
 
   // ---- halo staging: piece = (pixel, 4-channel group); a thread keeps one channel group (256 % 8 == 0) and 11 pixels.
-  // gp[i] = (pixel index + 1, 0 = outside the image) | (LDS float offset / 4) << 20, kept in the LDS behind the two halo images
+  // gp[i] = (pixel index + 1, 0 = outside the image) | (LDS offset in 16-byte units from 4 KB in front of the image) << 20, kept in the LDS behind the two halo images
   // ([piece][thread]: the registers are needed elsewhere) and read back one item ahead of its use
   const int sub = tid & 7;
-  int* gpL = reinterpret_cast<int*>(H0 + 2 * WHALO) + tid;
+  int* gpL = reinterpret_cast<int*>(H0 + WIMG + WHALO) + tid;
   int gpr[11];                                   // register copies for the prologue's loads
+  const int prow0 = b * p.Hin;
 #pragma unroll
   for (int it = 0; it < 11; ++it) {
     const int pix = min((tid >> 3) + 32 * it, 323);           // (the last round's surplus threads repeat pixel 323: same value, same place)
-    const int row = pix / 18, col = pix - row * 18;
+    // (24-bit multiplies throughout: a 32-bit v_mul_lo is a quarter-rate instruction, and this loop is on the critical path to the first load)
+    const int row = (int)__umul24(pix, 57) >> 10, col = pix - (int)__umul24(row, 18);          // pix / 18 for pix < 324
     const int iy = oy0 - 1 + row, ix = ox0 - 1 + col;
-    const int gpix = (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) ? (b * p.Hin + iy) * p.Win + ix + 1 : 0;
-    const int lo4 = (row * WRP + col * WPP) / 4 + (sub ^ ((row >> 1) & 1));
+    const bool inside = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+    const int gpix = inside ? (int)__umul24(prow0 + iy, p.Win) + ix + 1 : 0;
+    const int real4 = (int)__umul24(row, WRP / 4) + (int)__umul24(col, WPP / 4) + (sub ^ ((row >> 1) & 1));
+    const int lo4 = inside ? 256 + real4 : tid;           // in units of 16 bytes from 4 KB in front of the image
+    if (!inside) {                                        // zero padding applies to the ACTIVATED tensor: written once, never overwritten
+      *reinterpret_cast<f32x4*>(H0 + real4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(H0 + WIMG + real4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     gpr[it] = gpix | (lo4 << 20);
     gpL[it * 256] = gpr[it];
   }
@@ -372,21 +431,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
   };
   int gq = 0, gst = 0;                            // piece words read one item ahead of their use (an LDS read right before its use stalls the wave)
   auto gpRead = [&](int pi) { gq = gpL[pi * 256]; };
-  auto haloFetch = [&](int ct, int gpv) -> f32x4 {          // global load of the piece with word gpv of chunk ct
+  auto haloFetch = [&](int ct, int gpv, int skip = 0) -> f32x4 {          // global load of the piece with word gpv of chunk ct (skip = 1 << 31: no access)
     const int cg = ct * 32;
     const bool first = cg < p.c0;                // wave-uniform: the source tensor of this chunk
     const __amdgpu_buffer_rsrc_t rs = dma_resource(first ? px0 : px1);
     const int cs4 = (first ? p.c0 : p.c1) * 4, co4 = (first ? cg : cg - p.c0) * 4;
     const int gpix = (gpv & 0xFFFFF) - 1;
-    const int vo = gpix < 0 ? (int)0x80000000u : (int)__umul24(gpix, cs4) + sub * 16;     // outside: an offset >= the resource's size reads as zero, no access
+    // outside the image (gpix = -1): bit 31 set - an offset >= the resource's size reads as zero, no access (branch-free)
+    const int vo = ((int)__umul24(gpix, cs4) + sub * 16) | (gpix & (int)0x80000000u) | skip;
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, co4, 0));
   };
-  auto haloLoad = [&](int pi, int ct, int gpv) { ra[pi] = haloFetch(ct, gpv); };
+  auto haloLoad = [&](int pi, int ct, int gpv, int skip = 0) { ra[pi] = haloFetch(ct, gpv, skip); };
   auto stageWhole = [&](f32x4 r, f32x4 sc4, f32x4 sh4, int gpv, float* Ht) {     // prologue: a whole piece at once
     r = r * sc4 + sh4;
-    r[0] = silu_f(r[0]); r[1] = silu_f(r[1]); r[2] = silu_f(r[2]); r[3] = silu_f(r[3]);
-    const f32x4 v = (gpv & 0xFFFFF) ? r : f32x4{0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(Ht + (((unsigned)gpv >> 20) << 2)) = v;
+    const f32x2_ a = silu2(f32x2_{r[0], r[1]}), c2 = silu2(f32x2_{r[2], r[3]});
+    *reinterpret_cast<f32x4*>(Ht - 1024 + (((unsigned)gpv >> 20) << 2)) = f32x4{a[0], a[1], c2[0], c2[1]};
   };
   auto scLoad = [&](int ct) {
     vsc = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsSc, sub * 16, ct * 128, 0));
@@ -394,14 +453,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
   };
   auto stageA = [&](int pi) {                    // first half of a piece: normalise, SiLU of two elements
     gst = gpL[pi * 256];
-    ra[pi] = ra[pi] * vsc + vsh;
-    ra[pi][0] = silu_f(ra[pi][0]); ra[pi][1] = silu_f(ra[pi][1]);
+    const f32x2_ a = silu2(f32x2_{ra[pi][0], ra[pi][1]} * f32x2_{vsc[0], vsc[1]} + f32x2_{vsh[0], vsh[1]});
+    ra[pi][0] = a[0]; ra[pi][1] = a[1];
   };
-  auto stageB = [&](int pi, float* Ht) {         // second half + the LDS write (zero padding applies to the ACTIVATED tensor)
-    ra[pi][2] = silu_f(ra[pi][2]); ra[pi][3] = silu_f(ra[pi][3]);
-    const int gpv = gst;
-    const f32x4 v = (gpv & 0xFFFFF) ? ra[pi] : f32x4{0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(Ht + (((unsigned)gpv >> 20) << 2)) = v;
+  auto stageB = [&](int pi, float* Ht) {         // second half + the LDS write
+    const f32x2_ a = silu2(f32x2_{ra[pi][2], ra[pi][3]} * f32x2_{vsc[2], vsc[3]} + f32x2_{vsh[2], vsh[3]});
+    ra[pi][2] = a[0]; ra[pi][3] = a[1];
+    *reinterpret_cast<f32x4*>(Ht - 1024 + (((unsigned)gst >> 20) << 2)) = ra[pi];
   };
 
   // ---- A-operand side: lane = (tile m = lane & 31, channel group g = lane >> 5); B^T row of this wave: t = x + sigma * y
@@ -421,6 +479,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
     asm volatile("" : "+v"(ox_), "+v"(oy_));   // opaque (the compiler otherwise keeps - and spills - their many parts)
   }
   const SplitK spk = split_consts();
+  f32x2_ sig2 = {sigma, sigma};
+  asm volatile("" : "+v"(sig2));
   f32x4 rwx[2], rwy[2], tt[4];
   x3x4 fh_[2][4][2], fl_[2][4][2];              // input fragments [set][j][channel half]: hi | lo
   auto fragRead = [&](const float* Hn, int s, int h, int e, int b2) {     // pixels 2 * b2, 2 * b2 + 1 of the two rows
@@ -434,10 +494,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
   };
   auto fragT = [&](int b2) {
 #pragma unroll
-    for (int bb = 0; bb < 2; ++bb) tt[2 * b2 + bb] = rwx[bb] + sigma * rwy[bb];
+    for (int bb = 0; bb < 2; ++bb) tt[2 * b2 + bb] = fma4(rwy[bb], sig2, rwx[bb]);
   };
   auto fragV = [&](int set, int j, int e) {
-    const f32x4 v = j == 0 ? tt[0] - tt[2] : (j == 1 ? tt[1] + tt[2] : (j == 2 ? tt[2] - tt[1] : tt[1] - tt[3]));
+    const f32x4 v = j == 0 ? sub4(tt[0], tt[2]) : (j == 1 ? tt[1] + tt[2] : (j == 2 ? sub4(tt[2], tt[1]) : sub4(tt[1], tt[3])));
     split4(v, fh_[set][j][e], fl_[set][j][e], spk);
   };
 
@@ -453,9 +513,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
     }
   };
 
-  auto wLoad1 = [&](int j, int nb, bool lo, int kk) {
-    if (lo) bl[j][nb] = __builtin_bit_cast(x3x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, lane * 16, kk * wstep + ((j * 2 + nb) * 2 + 1) * 1024, 0));
-    else bh[j][nb] = __builtin_bit_cast(x3x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, lane * 16, kk * wstep + ((j * 2 + nb) * 2 + 0) * 1024, 0));
+  auto wLoad1 = [&](int j, int nb, bool lo, int kk, int skip) {
+    if (lo) bl[j][nb] = __builtin_bit_cast(x3x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, (lane * 16) | skip, kk * wstep + ((j * 2 + nb) * 2 + 1) * 1024, 0));
+    else bh[j][nb] = __builtin_bit_cast(x3x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, (lane * 16) | skip, kk * wstep + ((j * 2 + nb) * 2 + 0) * 1024, 0));
   };
   f32x16 acc[4][2][2];
 
@@ -466,31 +526,41 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
   {
     const int c1 = min(1, nchunk - 1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wLoad(j, 0);
+    for (int pi = 0; pi < 11; ++pi) haloLoad(pi, 0, gpr[pi]);   // (the longest latency first)
     scLoad(0);
     const f32x4 vsc0 = vsc, vsh0 = vsh;
+    f32x4 rb[3];
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) rb[pi] = haloFetch(c1, gpr[pi]);
     scLoad(c1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wLoad(j, 0);
     float tsc[4], tsh[4];                        // this thread's share of the rows (cin <= 1024)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = min(tid + 256 * i, cin - 1);
       tsc[i] = p.sc[(size_t)b * cin + c]; tsh[i] = p.sh[(size_t)b * cin + c];
     }
-#pragma unroll
-    for (int pi = 0; pi < 11; ++pi) haloLoad(pi, 0, gpr[pi]);
-    f32x4 rb[3];
-#pragma unroll
-    for (int pi = 0; pi < 3; ++pi) rb[pi] = haloFetch(c1, gpr[pi]);
     WTR();
     SB();
+    // the accumulators are cleared by the matrix pipe itself (0 x 0 + 0: 16 instructions that run beside the vector work, instead of 256
+    // register writes in front of it)
+    {
+      x3x8 z8;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int e = 0; e < 8; ++e) z8[e] = (x3_t)0.f;
+      asm volatile("" : "+v"(z8));
+      const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[j][h][nb][r] = 0.f;
+          for (int nb = 0; nb < 2; ++nb) {
+            asm volatile("" : "+v"(z8));       // (sixteen distinct instructions: identical ones are merged into one plus 240 register copies)
+            acc[j][h][nb] = x3_mfma_32x32x16(z8, z8, z16, 0, 0, 0);
+          }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       if (tid + 256 * i < cin) { scL[tid + 256 * i] = tsc[i]; shL[tid + 256 * i] = tsh[i]; }
@@ -499,7 +569,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
     for (int pi = 0; pi < 11; ++pi) stageWhole(ra[pi], vsc0, vsh0, gpr[pi], H0);
     WTR();
 #pragma unroll
-    for (int pi = 0; pi < 3; ++pi) stageWhole(rb[pi], vsc, vsh, gpr[pi], H0 + WHALO);
+    for (int pi = 0; pi < 3; ++pi) stageWhole(rb[pi], vsc, vsh, gpr[pi], H0 + WIMG);
 #pragma unroll
     for (int pi = 3; pi < 9; ++pi) haloLoad(pi, c1, gpr[pi]);
     WTR();
@@ -515,8 +585,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
 
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const int c1 = min(chunk + 1, nchunk - 1), c2 = min(chunk + 2, nchunk - 1);
-    float* Hcur = H0 + (chunk & 1) * WHALO;
-    float* Hnxt = H0 + ((chunk + 1) & 1) * WHALO;
+    // loads for chunks past the last one: issued all the same (branch-free steps), with an offset beyond the resource - no memory access
+    const int skip1 = chunk + 1 < nchunk ? 0 : (int)0x80000000u, skip2 = chunk + 2 < nchunk ? 0 : (int)0x80000000u;
+    float* Hcur = H0 + (chunk & 1) * WIMG;
+    float* Hnxt = H0 + ((chunk + 1) & 1) * WIMG;
     static_for<0, 4>([&](auto qc) {
       constexpr int QS = decltype(qc)::value, s = QS >> 1, h = QS & 1;
       constexpr int QN = (QS + 1) & 3, sn = QN >> 1, hn = QN & 1;       // the step whose fragments are produced now, into set hn
@@ -555,7 +627,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
         }
         if constexpr (k == 3 || k == 9 || k == 11) {
           constexpr int li = k == 3 ? 0 : (k == 9 ? 1 : 2);
-          if constexpr (li < lpn) haloLoad(lp0 + li, lct, gq);
+          if constexpr (li < lpn) haloLoad(lp0 + li, lct, gq, QS == 0 ? skip1 : skip2);
         }
         if constexpr (k == 1 || k == 7 || k == 9) {            // piece word, one slot ahead of the load that needs it
           constexpr int li = k == 1 ? 0 : (k == 7 ? 1 : 2);
@@ -564,7 +636,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
         if constexpr (k == 15) scRead(QS == 3 ? c2 : c1);
         // a weight fragment is re-loaded for the next 16 channels right after its last MFMA (lo plane: the hi.lo product, hi plane: hi.hi):
         // one load per slot - four in a row stall the wave on the address unit the four waves share
-        if constexpr (h == 1 && (k % 6) >= 2) wLoad1(j, k & 1, (k % 6) < 4, s == 0 ? chunk * 2 + 1 : c1 * 2);
+        if constexpr (h == 1 && (k % 6) >= 2) wLoad1(j, k & 1, (k % 6) < 4, s == 0 ? chunk * 2 + 1 : c1 * 2, s == 0 ? 0 : skip1);
         SB();
       });
     });
@@ -572,16 +644,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
 #undef SB
   WTR();
 #ifdef PF_TRACE
-  wino_epilogue(p, acc, smem_all, b, oy0, ox0, n0, ty_t, tx_t, wave, lane, tid, trace_on, tbase, tslot);
+  wino_epilogue(p, acc, smem_all, b, oy0, ox0, n0, ty_t, tx_t, wave, lane, tid, sbp, trace_on, tbase, tslot);
 #else
-  wino_epilogue(p, acc, smem_all, b, oy0, ox0, n0, ty_t, tx_t, wave, lane, tid);
+  wino_epilogue(p, acc, smem_all, b, oy0, ox0, n0, ty_t, tx_t, wave, lane, tid, sbp);
 #endif
 }
 
 bool conv_wino_eligible(const pf_conv_args& a) {
   return a.wino > 0 && a.w_wino && a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.stride == 1 && !a.ups && !a.ups_fold && a.prologue == 1 &&
          a.hin % 16 == 0 && a.win % 16 == 0 && a.n % 64 == 0 && a.c0 % 32 == 0 && a.c1 % 32 == 0 && !a.geglu && !a.out_planes && !a.qkv_planes &&
-         !a.skip_w && (a.ld_out & 3) == 0 && (!a.res || (a.ld_res & 3) == 0);
+         a.c0 + a.c1 <= 1024 && !a.skip_w && (a.ld_out & 3) == 0 && (!a.res || (a.ld_res & 3) == 0);
 }
 
 int launch_conv_wino(const pf_conv_args& a, hipStream_t stream) {
