@@ -274,11 +274,13 @@ def profiled_pass(unet, step_fn, x, t_step, n_steps, precision, dump=False):
     for it in range(n_steps):
         x = step_fn(x, t_step)
         torch.cuda.synchronize()
+        direct = unet.read_profile_direct()
         for i, (kind, ms, fl) in enumerate(unet.read_profile()):
             if dump and it == 0:
-                print(f"launch {i:3d} {KIND_NAMES[kind]:14s} {ms * 1e3:8.1f} us {fl / 1e9:8.2f} GF {fl / max(ms, 1e-9) / 1e9:7.1f} TF/s", file=sys.stderr)
-            a = agg.setdefault(kind, [0, 0.0, 0.0])
-            a[0] += 1; a[1] += ms; a[2] += fl
+                print(f"launch {i:3d} {KIND_NAMES[kind]:14s} {ms * 1e3:8.1f} us {fl / 1e9:8.2f} GF {fl / max(ms, 1e-9) / 1e9:7.1f} TF/s"
+                      + (f"   (Winograd: direct form {direct[i] / 1e9:.2f} GF)" if direct[i] != fl else ""), file=sys.stderr)
+            a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0, 0])
+            a[0] += 1; a[1] += ms; a[2] += fl; a[3] += direct[i]; a[4] += int(direct[i] != fl)
     unet.set_profiling(False)
     return x, agg
 
@@ -425,25 +427,17 @@ def config4_line(steps=20, windows=3, probe=None):
 
 
 def long_parity_note(model, measure: bool):
-    """The three full-length f32-vs-bf16x3 comparisons (tools/long_parity.py; tests/test_gpu_long_parity.py asserts their bounds).  Config 3
-    (50 DDIM steps, guidance 5, B = 32: ~4 s) is re-measured in this run when `measure`; the two 1000-step ones (19 s and 37 s) are quoted from
-    the committed record of the same code path, profiles/r05_long_parity.json."""
+    """The full-length f32-vs-bf16x3 comparison of config 3 (50 DDIM steps, guidance 5, B = 32: ~4 s; tools/long_parity.py), measured in this run
+    when `measure`.  Nothing cached goes into the line: the 1000-step comparisons live in the GPU suite (tests/test_gpu_long_parity.py)."""
     keep = lambda r: {"final_max_abs": r["max_abs"], "final_rms": r["rms"], "image_rms": r["ref_rms"], "image_max_abs": r["ref_max_abs"],
                       "notes": r["notes"], "curve_max_abs_last": r["curve_max_abs"][-1][2], "what": r["what"]}
     out = {}
-    path = os.path.join(REPO, "profiles", "r05_long_parity.json")
-    rec = json.load(open(path)) if os.path.exists(path) else {}
-    for k in ("config2", "config5"):
-        if k in rec:
-            out[k] = dict(keep(rec[k]), source="profiles/r05_long_parity.json")
     if measure:
         try:
             from tools import long_parity
             out["config3"] = dict(keep(long_parity.config3(model)), source="measured in this run")
         except Exception as e:   # never lose the bench line to a diagnostic
             out["config3_error"] = f"{type(e).__name__}: {e}"
-    if "config3" not in out and "config3" in rec:
-        out["config3"] = dict(keep(rec["config3"]), source="profiles/r05_long_parity.json")
     return out
 
 
@@ -465,7 +459,7 @@ def main():
                     help="arithmetic of the dense contractions: exact fp32 MFMA, or the error-compensated bf16x3 split")
     ap.add_argument("--dump-launches", action="store_true", help="print one line per kernel launch of a profiled step (stderr)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=0|1",
-                    help="pin a plan option of the UNet handle (pf_unet_set_option: mlp_fused, attn_wide, conv_t16, conv_pp, pre_fused) for A/B runs; "
+                    help="pin a plan option of the UNet handle (pf_unet_set_option: mlp_fused, attn_wide, conv_t16, conv_pp, pre_fused, conv_wino) for A/B runs; "
                          "the default line runs with every option automatic")
     args = ap.parse_args()
 
@@ -551,7 +545,7 @@ def main():
         "path_tflops": round(f_eval * BATCH * world * args.steps / elapsed / 1e12, 3),
         "path_frac_of_f32_mfma_peak": round(f_eval * BATCH * args.steps / elapsed / (PEAK_F32_MFMA_TFLOPS * 1e12), 4),
         "path_flops_per_sample_eval": f_eval,
-        "plan_options": {n: unet.get_option(n) for n in ("mlp_fused", "attn_wide", "conv_t16", "conv_pp", "pre_fused")},
+        "plan_options": {n: unet.get_option(n) for n in ("mlp_fused", "attn_wide", "conv_t16", "conv_pp", "pre_fused", "conv_wino")},
         "precision_note": ("dense contractions on the bf16 matrix pipe as an error-compensated split (3 MFMAs per product, fp32 accumulate); "
                            "UNet max-abs-diff vs the reference 5.2e-5 (contract 1e-3)") if args.precision == "bf16x3"
         else "dense contractions on the fp32 matrix pipe (exact fp32 FMA chains)",
@@ -592,6 +586,11 @@ def main():
                                "launches_per_step": k[0] // args.profile_steps,
                                "avg_launch_ms": round(k[1] / k[0], 4),
                                "flops_per_step": k[2] / args.profile_steps,
+                               # the same family priced as if every layer ran its direct form: comparable between plans and rounds
+                               # (achieved / frac count the operations actually executed - Winograd launches run 16 / 36 of the direct count)
+                               "direct_equivalent_tflops": round(k[3] / (k[1] * 1e-3) / 1e12, 3),
+                               "direct_equivalent_flops_per_step": k[3] / args.profile_steps,
+                               "winograd_launches_per_step": k[4] // args.profile_steps,
                                "event_pair_overhead_ms": round(ev_pair_ms, 5),
                                "achieved_event_corrected": round(ach_corr, 3), "frac_event_corrected": round(ach_corr / peak, 4),
                                "timing_note": "hipEvents around every launch on the launch stream. An event pair adds its own cost to what it "
@@ -609,6 +608,11 @@ def main():
         out["kernel_ms_per_step_corrected"] = {KIND_NAMES[kind]: round(max(v[1] - v[0] * ev_pair_ms, 0.0) / args.profile_steps, 4)
                                                for kind, v in sorted(agg.items())}
         out["kernel_ms_per_step_corrected"]["sum"] = round(sum(out["kernel_ms_per_step_corrected"].values()), 4)
+        # everything that is not a 3x3 convolution (transformer linears, attention, norms, stem / head, sampler update): time and rate
+        nonconv_ms = sum(max(v[1] - v[0] * ev_pair_ms, 0.0) for kind, v in agg.items() if kind != 0) / args.profile_steps
+        nonconv_fl = sum(v[2] for kind, v in agg.items() if kind != 0) / args.profile_steps
+        out["nonconv_ms_per_step"] = round(nonconv_ms, 4)
+        out["nonconv_frac_of_833"] = round(nonconv_fl / max(nonconv_ms * 1e-3, 1e-12) / 1e12 / PEAK_ALGO["bf16x3"], 4) if args.precision == "bf16x3" else None
 
     if args.fp32_steps > 0 and args.precision == "bf16x3":
         # the exact-fp32-MFMA mode in the same run, same workload, the headline's protocol (every rank runs it so the barriers line up)
@@ -684,11 +688,12 @@ def main():
     if rank == 0 and args.precision == "bf16x3":
         out["long_parity"] = long_parity_note(model, measure=(world == 1 and not args.no_long_parity and args.small_batch_steps > 0))
         lp = out["long_parity"]
-        if all(k in lp for k in ("config2", "config3", "config5")):
-            out["precision_note"] += ("; full-length loops f32 vs bf16x3 on one noise tape (final max-abs-diff / differing note cells): "
-                                      + ", ".join(f"{k} {lp[k]['final_max_abs']:.1e} of images at rms {lp[k]['image_rms']:.0f} / "
-                                                  f"{lp[k]['notes']['onset_bits_differ'] + lp[k]['notes']['sustain_bits_differ']} of {2 * lp[k]['notes']['cells']}"
-                                                  for k in ("config2", "config3", "config5")))
+        if "config3" in lp:
+            k = lp["config3"]
+            out["precision_note"] += (f"; full-length config 3 loop f32 vs bf16x3 on one noise tape, measured in this run: final max-abs-diff {k['final_max_abs']:.1e} of images "
+                                      f"at rms {k['image_rms']:.0f}, {k['notes']['onset_bits_differ'] + k['notes']['sustain_bits_differ']} of {2 * k['notes']['cells']} note cells differ")
+        out["precision_note"] += ("; the 1000-step loops (configs 2 / 5) and all three against the REAL reference: tests/test_gpu_long_parity.py, "
+                                  "tests/test_gpu_long_reference.py (source: the GPU suite, not this run)")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(params)
     if rank == 0:

@@ -102,7 +102,7 @@ int pf_unet_forward_prepared(pf_unet* u, const float* x, const int64_t* t, const
  * without attention, the first ResBlock of the first attention level - is IDENTICAL for the two halves.  This entry computes that prefix once on
  * the `batch2 / 2` samples of `x`, shares the skip tensors it produced between the halves (a sample index taken modulo batch2 / 2 inside the
  * consuming kernels: no copies) and runs the rest on all batch2 samples: the same eps2 [batch2, ...] as pf_unet_forward_prepared on the
- * concatenated inputs up to tile-choice rounding, for 13 %% fewer FLOPs at sdf_chd8bar.  x: [batch2 / 2, ...]; t, cond (and prep->cross_bias): batch2
+ * concatenated inputs up to tile-choice rounding, for 13 % fewer FLOPs at sdf_chd8bar.  x: [batch2 / 2, ...]; t, cond (and prep->cross_bias): batch2
  * rows, second half = first half for t.  Workspace: pf_unet_workspace_bytes_cfg(u, batch2, n_cond) bytes. */
 size_t pf_unet_workspace_bytes_cfg(const pf_unet* u, int batch2, int n_cond);
 int pf_unet_forward_cfg(pf_unet* u, const float* x, const int64_t* t, const float* cond, int batch2, int n_cond,
@@ -121,8 +121,11 @@ int pf_unet_n_launches_prepared(const pf_unet* u, int batch, int n_cond, int has
  *                       two wave groups split K and run half a tap apart, one loading while the other computes (equal up to summation order)
  *   PF_OPT_PRE_FUSED  - the pre-attention half of a SpatialTransformer's first layer (GroupNorm + proj_in + LayerNorm1 + q|k|v projection,
  *                       pf_preattn_fused) as ONE launch per 64-token tile vs three launches; equal up to summation order; auto = off
- *                       (measured neutral end to end, profiles/r05_ab_pre_fused.md); on: every block with d_model 256 and L % 64 == 0 */
-enum { PF_OPT_MLP_FUSED = 0, PF_OPT_ATTN_WIDE = 1, PF_OPT_CONV_T16 = 2, PF_OPT_CONV_PP = 3, PF_OPT_PRE_FUSED = 4, PF_OPT_COUNT = 5 };
+ *                       (measured neutral end to end, profiles/r05_ab_pre_fused.md); on: every block with d_model 256 and L % 64 == 0
+ *   PF_OPT_CONV_WINO  - ResBlock 3x3 convs in the fused Winograd F(2x2, 3x3) form (pf_conv_args.wino; bf16x3 / f16x3 modes; equal to the direct
+ *                       form up to rounding, 2.25x fewer matrix operations) vs the direct implicit GEMM; auto: where it measured faster
+ *                       (profiles/r06_ab_winograd.md: input channels >= 192, or >= 128 at 32x32 and below); on: every conv that qualifies */
+enum { PF_OPT_MLP_FUSED = 0, PF_OPT_ATTN_WIDE = 1, PF_OPT_CONV_T16 = 2, PF_OPT_CONV_PP = 3, PF_OPT_PRE_FUSED = 4, PF_OPT_CONV_WINO = 5, PF_OPT_COUNT = 6 };
 enum { PF_OPT_AUTO = -1, PF_OPT_OFF = 0, PF_OPT_ON = 1 };
 int pf_unet_set_option(pf_unet* u, int option, int value);
 int pf_unet_get_option(const pf_unet* u, int option);
@@ -133,6 +136,9 @@ int pf_unet_get_option(const pf_unet* u, int option);
 enum { PF_K_CONV3 = 0, PF_K_GEMM = 1, PF_K_ATTN = 2, PF_K_GNSTAT = 3, PF_K_LNSTAT = 4, PF_K_SMALL = 5, PF_K_COUNT = 6 };
 int pf_unet_set_profiling(pf_unet* u, int enabled);
 int pf_unet_profile_read(pf_unet* u, int* kind, float* ms, double* flops, int capacity);
+/* the same launches' operation counts in the DIRECT form of each layer: equal to `flops` except for Winograd launches (PF_OPT_CONV_WINO), whose
+ * `flops` are the 16 / 36 actually executed - keeps achieved rates comparable between plans (bench.py: direct_equivalent_tflops) */
+int pf_unet_profile_read_direct(pf_unet* u, double* direct_flops, int capacity);
 int pf_unet_n_launches(const pf_unet* u, int batch, int n_cond);
 
 /* ---- sampler steps (elementwise, NCHW fp32, n = B*C*H*W elements) -------------------------
@@ -266,7 +272,7 @@ int pf_pack_gemm_weight(const float* w, int n, int k, int taps, float* dst);
 int pf_pack_gemm_weight_bf16x3(const float* w, int n, int k, int taps, void* dst);
 /* [n][k][3][3] conv weight of an UpSample layer -> folded packing [4 parities x 4 taps][k/8][plane][Npad][8] (host; k % 8 == 0) */
 int pf_pack_upfold_weight_bf16x3(const float* w, int n, int k, void* dst);
-/* Winograd F(2x2, 3x3) packing of a 3x3 conv weight [n][k][3][3] (n %% 64 == 0, k %% 16 == 0) for pf_conv_args.w_wino: U = G g G^T per (n, k),
+/* Winograd F(2x2, 3x3) packing of a 3x3 conv weight [n][k][3][3] (n % 64 == 0, k % 16 == 0) for pf_conv_args.w_wino: U = G g G^T per (n, k),
  * split into hi | lo pieces, laid out in matrix-operand order; pf_wino_weight_bytes(n, k) = 16 * k * n * 4 bytes */
 size_t pf_wino_weight_bytes(int n, int k);
 int pf_pack_wino_weight_bf16x3(const float* w, int n, int k, void* dst);
@@ -283,7 +289,7 @@ int pf_ln_stats(const float* x, int rows, int c, float eps, float* mean, float* 
 int pf_ln_planes(const float* x, int rows, int c, float eps, const float* gamma, const float* beta, void* planes, void* stream);
 /* The feed-forward half of BasicTransformerBlock as ONE launch (unet_attention.py:119-124 `x = ff(norm3(x)) + x`, :296-333 FeedForward /
  * GeGLU) for d_model 256, hidden 1024, bf16x3 arithmetic:  out = x + W2 . (a * gelu(g)) + b2 with [a|g] = W1 . LayerNorm(x) + b1.
- * x fp32 [batch*l][256], l %% 64 == 0.  w1_bf16x3: the bf16x3 packing (pf_pack_gemm_weight_bf16x3) of ff.net.0.proj with its 2048 rows
+ * x fp32 [batch*l][256], l % 64 == 0.  w1_bf16x3: the bf16x3 packing (pf_pack_gemm_weight_bf16x3) of ff.net.0.proj with its 2048 rows
  * reordered value/gate-interleaved in blocks of 32 (row 64 i + j <- value 32 i + j, row 64 i + 32 + j <- gate 32 i + j), b1 in the same
  * order; w2_bf16x3: packing of ff.net.2 ([256][1024]).  The result goes to fp32 `out` or, when out_planes != NULL, to bf16 hi/lo planes
  * [M][256] | [M][256].  Bit-identical to pf_ln_planes + pf_conv2d(geglu, out_planes) + pf_conv2d(a_planes, res = x). */
@@ -354,10 +360,10 @@ typedef struct pf_conv_args {
   int32_t no_t16;          /* != 0: never pick the 16x16-pixel tile (PF_OPT_CONV_T16 = off) */
   int32_t no_pp;           /* != 0: never run the two-group ping-pong form of the 128-wide tile (PF_OPT_CONV_PP = off) */
   /* measurement aids (tools/sweep_conv.py): 0 = the library's own choice.  force_tile: 1 + tile index (1: 128 px x 128 ch, 2: 128 px x 64 ch,
-   * 3: 64 px x 64 ch; bf16x3 3x3 stride 1 and planes GEMMs without GeGLU, tile 1 needs n %% 128 == 0); force_ksplit: K slices across workgroups (bf16x3 3x3 stride 1,
+   * 3: 64 px x 64 ch; bf16x3 3x3 stride 1 and planes GEMMs without GeGLU, tile 1 needs n % 128 == 0); force_ksplit: K slices across workgroups (bf16x3 3x3 stride 1,
    * must divide the 32-channel chunks; > 1 needs splitk_ws).  Results are the same up to summation order. */
   int32_t force_tile, force_ksplit;
-  /* > 0: the SECOND sources (x1, skip_x1, gn_stats1) hold only x1_bmod samples; sample b reads sample b %% x1_bmod of them (the shared skip
+  /* > 0: the SECOND sources (x1, skip_x1, gn_stats1) hold only x1_bmod samples; sample b reads sample b % x1_bmod of them (the shared skip
    * tensors of pf_unet_forward_cfg) */
   int32_t x1_bmod;
   /* Fused Winograd F(2x2, 3x3) form of the ResBlock conv (bf16x3, ks = 3, stride 1, prologue 1, hin / win multiples of 16, n a multiple
@@ -377,12 +383,12 @@ int pf_conv2d(const pf_conv_args* a, void* stream);
 
 /* softmax(q k^T * d_head^-0.5) v per (batch, head); q [B,Lq,*], k/v [B,Lk,*] with row strides ld*, heads packed
  * along the last dim (unet_attention.py:261-293). d_head in {32,64}. */
-/* self-attention on the pre-split planes written by pf_conv2d(qkv_planes=...): d_head 64, L %% 128 == 0 (bf16x3 split MFMA);
+/* self-attention on the pre-split planes written by pf_conv2d(qkv_planes=...): d_head 64, L % 128 == 0 (bf16x3 split MFMA);
  * the result goes to fp32 `o` or, when o_planes != NULL, to bf16 hi/lo planes [M][C] | [M][C] for a following planes GEMM */
 int pf_attention_bf16x3(const void* qkv_planes, float* o, int ldo, void* o_planes, int batch, int n_heads, int l, int form /* PF_OPT_AUTO | 0: 128-query | 1: 256-query workgroups */,
                         void* stream);
 /* The same attention for SMALL batches (128-query form): when (l / 128) * n_heads * batch workgroups would leave three quarters of the CUs idle and
- * l %% 512 == 0 (batch 1 / 2 at L = 1024), the keys of every query tile are split over four workgroups - each leaves its un-normalised partial result,
+ * l % 512 == 0 (batch 1 / 2 at L = 1024), the keys of every query tile are split over four workgroups - each leaves its un-normalised partial result,
  * running maximum and row sum in `scratch` - and a second launch merges them (the online-softmax combination; equal to the one-launch form up to
  * summation order).  scratch_bytes >= pf_attention_split_scratch_bytes(batch, n_heads, l) (0 = this shape does not split: one launch, scratch unused). */
 size_t pf_attention_split_scratch_bytes(int batch, int n_heads, int l);

@@ -61,8 +61,8 @@ class UNetPrepared(C.Structure):
     _fields_ = [("time_table", C.c_void_p), ("n_time_rows", C.c_int32), ("cross_bias", C.c_void_p)]
 
 
-OPT_MLP_FUSED, OPT_ATTN_WIDE, OPT_CONV_T16, OPT_CONV_PP, OPT_PRE_FUSED = 0, 1, 2, 3, 4
-OPT_COUNT = 5              # PF_OPT_COUNT
+OPT_MLP_FUSED, OPT_ATTN_WIDE, OPT_CONV_T16, OPT_CONV_PP, OPT_PRE_FUSED, OPT_CONV_WINO = 0, 1, 2, 3, 4, 5
+OPT_COUNT = 6              # PF_OPT_COUNT
 OPT_AUTO, OPT_OFF, OPT_ON = -1, 0, 1
 
 
@@ -121,6 +121,7 @@ SIGNATURES = {
     "pf_unet_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pf_unet_get_option": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_unet_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "pf_unet_profile_read_direct": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "pf_unet_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), c_float_p, C.POINTER(C.c_double), C.c_int]),
     "pf_unet_n_launches": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pf_cfg_combine": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -329,7 +329,8 @@ double conv_flops(const pf_conv_args& a) {
     if (a.stride == 2) { hout = (hout - 1) / 2 + 1; wout = (wout - 1) / 2 + 1; }
   }
   const double skip = a.skip_w ? (double)(a.skip_c0 + a.skip_c1) : 0.0;   // fused 1x1 projection of a second tensor
-  const double taps = a.ups_fold ? 4.0 : (double)(a.ks * a.ks);   // folded upsampling conv: 2x2 taps per output pixel (work actually done)
+  // folded upsampling conv: 2x2 taps per output pixel; Winograd F(2x2, 3x3): 16 products per 2x2 output pixels (work actually done)
+  const double taps = (a.ups_fold || conv_wino_eligible(a)) ? 4.0 : (double)(a.ks * a.ks);
   return 2.0 * a.batch * hout * wout * (double)a.n * (cin * taps + skip);
 }
 

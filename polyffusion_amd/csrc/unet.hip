@@ -27,16 +27,18 @@ int set_error(int code, const char* fmt, ...) {
   return code;
 }
 
-enum DestKind { D_RAW = 0, D_GEMM = 1, D_GEGLU_W = 2, D_GEGLU_B = 3, D_CONVOUT = 4, D_UPFOLD = 5 };
+enum DestKind { D_RAW = 0, D_GEMM = 1, D_GEGLU_W = 2, D_GEGLU_B = 3, D_CONVOUT = 4, D_UPFOLD = 5, D_WINO = 6 };
 struct Dest { int kind; size_t off; int taps, K, N, Npad, n_off; };
 struct ParamSpec { std::string key; std::vector<int64_t> shape; std::vector<Dest> dests; bool packed = false; };
 
 struct Layer {
   int kind;  // 0 conv_in, 1 res, 2 st, 3 down, 4 up
   int cin, cout;
+  int hw_h = 0, hw_w = 0;                                             // res: spatial size of the level (decides whether the Winograd packings exist)
   // offsets (floats) into the packed blob
   size_t gn1_g, gn1_b, w1, b1, gn2_g, gn2_b, w2, b2, wskip, bskip;  // res; conv: w1/b1
   size_t wfold = 0;                                                   // upsample: parity-folded bf16x3 packing (16 taps)
+  size_t wino1 = 0, wino2 = 0;                                        // res: Winograd packings of the two 3x3 convs (0: none)
   int emb_off;                                                        // column offset into the all-ResBlock time-bias matrix
   // spatial transformer
   size_t norm_g, norm_b, pin_w, pin_b, pout_w, pout_b;
@@ -68,13 +70,13 @@ struct pf_unet {
   int cross_cursor = 0;
   size_t cross_o_cursor = 0;
   const float* wdev = nullptr;
-  int opt[PF_OPT_COUNT] = {PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO};   // pf_unet_set_option
+  int opt[PF_OPT_COUNT] = {PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO};   // pf_unet_set_option
   // profiling
   int precision = PF_PREC_F32;
   bool profiling = false;
   std::vector<hipEvent_t> ev;
   std::vector<int> pkind;
-  std::vector<double> pflops;
+  std::vector<double> pflops, pdirect;   // per launch: operations executed / operations of the direct form (differ for Winograd launches)
   int n_prof = 0;
 
   size_t alloc(size_t nfloats) { size_t o = blob_floats; blob_floats += (nfloats + 63) / 64 * 64; return o; }
@@ -111,12 +113,22 @@ static void build_res(pf_unet* u, const std::string& p, Layer& L) {
   L.gn1_g = u->add_raw(p + ".in_layers.0.weight", {ci});
   L.gn1_b = u->add_raw(p + ".in_layers.0.bias", {ci});
   L.w1 = u->add_gemm(p + ".in_layers.2.weight", co, ci, 9);
+  // the Winograd F(2x2, 3x3) packing beside it where the fused form can run (conv_wino.hip: 16x16-pixel tiles, 64-channel blocks)
+  const bool wino_ok = L.hw_h >= 32 && L.hw_w >= 32 && L.hw_h % 16 == 0 && L.hw_w % 16 == 0 && co % 64 == 0 && ci % 32 == 0 && ci <= 1024;
+  if (wino_ok) {
+    L.wino1 = u->alloc((size_t)16 * ci * co);
+    u->params.back().dests.push_back(Dest{D_WINO, L.wino1, 9, ci, co, co, 0});
+  }
   L.b1 = u->add_raw(p + ".in_layers.2.bias", {co});
   L.emb_off = u->sum_emb;
   u->sum_emb += co;
   L.gn2_g = u->add_raw(p + ".out_layers.0.weight", {co});
   L.gn2_b = u->add_raw(p + ".out_layers.0.bias", {co});
   L.w2 = u->add_gemm(p + ".out_layers.3.weight", co, co, 9);
+  if (wino_ok && ci == co) {   // (a channel-changing block folds its 1x1 skip projection into this conv: direct form only)
+    L.wino2 = u->alloc((size_t)16 * co * co);
+    u->params.back().dests.push_back(Dest{D_WINO, L.wino2, 9, co, co, co, 0});
+  }
   L.b2 = u->add_raw(p + ".out_layers.3.bias", {co});
   if (ci != co) {
     L.wskip = u->add_gemm(p + ".skip_connection.weight", co, ci, 1);
@@ -229,7 +241,7 @@ static int build(pf_unet* u) {
   for (int lvl = 0; lvl < c.n_levels; ++lvl) {
     const bool att = in_list(c.attention_levels, c.n_attention_levels, lvl);
     for (int r = 0; r < c.n_res_blocks; ++r) {
-      Block b; Layer L{}; L.kind = 1; L.cin = ch; L.cout = widths[lvl]; b.layers.push_back(L);
+      Block b; Layer L{}; L.kind = 1; L.cin = ch; L.cout = widths[lvl]; L.hw_h = c.img_h >> lvl; L.hw_w = c.img_w >> lvl; b.layers.push_back(L);
       ch = widths[lvl];
       if (att) {
         PF_REQUIRE(ch % c.n_heads == 0 && (ch / c.n_heads == 32 || ch / c.n_heads == 64), "unet: d_head %d unsupported (32 or 64)", ch / c.n_heads);
@@ -254,7 +266,7 @@ static int build(pf_unet* u) {
     for (int j = 0; j <= c.n_res_blocks; ++j) {
       const int sk = stack.back(); stack.pop_back();
       u->skip_ch.push_back(sk);
-      Block b; Layer L{}; L.kind = 1; L.cin = ch + sk; L.cout = widths[lvl]; b.layers.push_back(L);
+      Block b; Layer L{}; L.kind = 1; L.cin = ch + sk; L.cout = widths[lvl]; L.hw_h = c.img_h >> lvl; L.hw_w = c.img_w >> lvl; b.layers.push_back(L);
       ch = widths[lvl];
       if (att) { Layer S{}; S.kind = 2; S.cin = S.cout = ch; b.layers.push_back(S); }
       if (lvl != 0 && j == c.n_res_blocks) { Layer U{}; U.kind = 4; U.cin = U.cout = ch; b.layers.push_back(U); }
@@ -341,6 +353,7 @@ static int pack_one(const ParamSpec& ps, const float* src, float* blob) {
         if (d.K % 8 == 0) fits = pack_gemm_bf3(dst + (size_t)d.taps * d.K * d.Npad, src, d.N, d.K, d.taps, d.Npad, d.n_off, nullptr) && fits;
         break;
       case D_UPFOLD: fits = pack_upfold_bf3(dst, src, d.N, d.K, d.Npad) && fits; break;
+      case D_WINO: fits = pack_wino_bf3(dst, src, d.N, d.K) && fits; break;
       case D_GEGLU_W: {
         const int inner = d.N / 2;
         for (int n = 0; n < d.N; ++n)
@@ -401,9 +414,10 @@ struct Ctx {
   void treset() { temp_off = 0; }
   const float* w(size_t off) const { return dry ? nullptr : W + off; }
 
-  void prof_begin(int kind, double flops) {
+  void prof_begin(int kind, double flops, double direct = -1.0) {
     ++n_launch;
     if (dry || !u->profiling) return;
+    u->pdirect.push_back(direct < 0.0 ? flops : direct);
     const size_t need = (size_t)(u->n_prof + 1) * 2;
     while (u->ev.size() < need) { hipEvent_t e; (void)hipEventCreate(&e); u->ev.push_back(e); }
     u->pkind.push_back(kind); u->pflops.push_back(flops);
@@ -432,7 +446,9 @@ struct Ctx {
       a.stats_out = sb;
       stats->d = a.out; stats->c = a.n; stats->st = sb; stats->nt = nt;
     }
-    prof_begin(kind, conv_flops(a));
+    double direct = -1.0;
+    if (a.wino) { pf_conv_args d = a; d.wino = 0; direct = conv_flops(d); }
+    prof_begin(kind, conv_flops(a), direct);
     if (!dry && rc == PF_OK) {
       if (w_bf3) a.w = w_bf3;                                                       // a packing of its own (folded upsampling conv)
       else if (bf3) a.w = a.w + (size_t)a.ks * a.ks * cin_ * ((a.n + 63) / 64 * 64);  // second half of the region = bf16x3 packing
@@ -455,6 +471,21 @@ struct Ctx {
     }
     gn_launch(x0, x1, hw, eps, g, b_, sc, sh);
     return GnRef{};
+  }
+  // the fused Winograd form of a ResBlock conv (PF_OPT_CONV_WINO).  AUTO follows the same-box A/B of profiles/r06_ab_winograd.md: the form
+  // wins where the K loop is long enough to carry its per-tile exchange - 192 input channels and more, or 128 and more from the 32x32 level
+  // down - and when its 16x16-pixel x 64-channel workgroups fill at least three quarters of the CUs.
+  void wino_attach(pf_conv_args& a, size_t wino_off) {
+    const int o = u->opt[PF_OPT_CONV_WINO];
+    if (!wino_off || o == PF_OPT_OFF || u->precision != PF_PREC_BF16X3) return;
+    const int cin_ = a.c0 + a.c1;
+    if (o == PF_OPT_AUTO) {
+      const int wgs = a.batch * (a.hin / 16) * (a.win / 16) * (a.n / 64);
+      const bool deep = cin_ >= 192 || (cin_ >= 128 && a.hin * a.win <= 1024);
+      if (!deep || wgs * 4 < num_cus() * 3) return;
+    }
+    a.w_wino = dry ? (const void*)16 : (const void*)w(wino_off);
+    a.wino = 1;
   }
   void gn_attach(pf_conv_args& a, const GnRef& r) {
     if (!r.fused) return;
@@ -513,6 +544,7 @@ static Tn run_res(Ctx& c, const Layer& L, const Tn& x0, const Tn& x1, int H, int
     a.sbias = c.dry ? nullptr : tb_all + L.emb_off; a.ld_sbias = c.u->sum_emb;
     a.sbias_rows = c.t_rows; a.sbias_nrows = c.prep_time_rows;   // hoisted table: row = t[b]
     a.x1_bmod = c.x1mod(x1);
+    c.wino_attach(a, L.wino1);
     c.conv(a, PF_K_CONV3, &ht, false);
   }
   const Ctx::GnRef g2 = c.gn(ht, Tn{}, hw, 1e-5f, L.gn2_g, L.gn2_b, sc2, sh2, true);
@@ -541,6 +573,7 @@ static Tn run_res(Ctx& c, const Layer& L, const Tn& x0, const Tn& x1, int H, int
     } else {
       a.res = res; a.ld_res = co;
     }
+    c.wino_attach(a, L.wino2);
     c.conv(a, PF_K_CONV3, &ot, true);
   }
   return ot;
@@ -1085,7 +1118,7 @@ int pf_x3_element(void) {
 int pf_unet_set_profiling(pf_unet* u, int enabled) {
   PF_REQUIRE(u, "null handle");
   u->profiling = enabled != 0;
-  u->n_prof = 0; u->pkind.clear(); u->pflops.clear();
+  u->n_prof = 0; u->pkind.clear(); u->pflops.clear(); u->pdirect.clear();
   return PF_OK;
 }
 
@@ -1098,6 +1131,13 @@ int pf_unet_profile_read(pf_unet* u, int* kind, float* ms, double* flops, int ca
     PF_CHECK_HIP(hipEventElapsedTime(&v, u->ev[(size_t)i * 2], u->ev[(size_t)i * 2 + 1]));
     kind[i] = u->pkind[i]; ms[i] = v; flops[i] = u->pflops[i];
   }
+  return n;
+}
+
+int pf_unet_profile_read_direct(pf_unet* u, double* direct_flops, int capacity) {
+  PF_REQUIRE(u && direct_flops, "pf_unet_profile_read_direct: null argument");
+  const int n = u->n_prof < capacity ? u->n_prof : capacity;
+  for (int i = 0; i < n; ++i) direct_flops[i] = u->pdirect[i];
   return n;
 }
 

@@ -136,7 +136,7 @@ class DataSample:
 
 
 # ---- validation-set song files (ref:data/dataset.py:27-253, data/dataset_musicalion.py:25-208) ----------------------------------------
-# PARITY UNPINNED: the POP909 / Musicalion .npz collections are not part of the reference checkout (only the split lists under
+# PINNED ON SYNTHETIC FILES OF THE DOCUMENTED LAYOUT (tests/golden/dataset.npz): the POP909 / Musicalion .npz collections are not part of the reference checkout (only the split lists under
 # data/train_split_pnt/ are) and no fixture of the reference holds one of their files; the classes below restate the reference's
 # loaders for the file layout those loaders read; tests/test_datasample.py holds them, bit for bit, to what the REAL reference loaders
 # returned on synthetic files of that layout (tests/golden/dataset.npz, tools/make_goldens_dataset.py).

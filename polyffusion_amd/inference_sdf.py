@@ -440,8 +440,11 @@ def load_model(params, args, rank: int = 0, world: int = 1) -> Polyffusion_SDF:
         except (SystemExit, Exception) as e:   # noqa: BLE001 - re-raised below on every rank
             failure = e
     if pfdist.broadcast_int(0 if failure is None else 1) != 0:
+        # ONE exception type on every rank (callers that fall back - `--precision auto` - must take the same branch everywhere)
         if failure is not None:
-            raise failure
+            if isinstance(failure, SystemExit):
+                raise failure
+            raise SystemExit(f"could not load the model weights: {type(failure).__name__}: {failure}") from failure
         raise SystemExit("rank 0 could not load the model weights (see its message)")
     for name, mod, nbytes in parts:
         blob = blobs[name] if rank == 0 else torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
@@ -526,7 +529,17 @@ def main(argv=None):
             params.setdefault("cond_mode", "cond")
             params.setdefault("use_enc", True)
     say(f"model_label: {params.model_name}")
-    model = load_model(params, args, rank, world)
+    try:
+        model = load_model(params, args, rank, world)
+    except SystemExit as e:
+        if args.precision != "auto-f16x3":
+            raise
+        # the fp16-split library refused the checkpoint (a weight beyond its packing's range): the exact mode of the default library instead
+        say(f"f16x3 not available for this checkpoint ({e}); loading it into the default library, precision f32")
+        import copy
+        args = copy.copy(args)
+        args.precision = "f32"
+        model = load_model(params, args, rank, world)
 
     length = args.length
     # prmat2c_cond: the CONDITION song's image (what concat_blurry blurs, ref:inference_sdf.py:797-803 uses `prmat2c`);
@@ -652,7 +665,9 @@ def main(argv=None):
             mode, ratio = pick_precision(mdl.ldm.eps_model, cond.reshape(-1, *cond.shape[-2:]), n_steps=params.n_steps, seed=seed)
             mode = ["f32", split][pfdist.broadcast_int(int(mode == split))]        # one decision for all ranks (rank 0's)
             mdl.ldm.eps_model.set_precision(mode)
-            say(f"precision: {mode} ({split} vs f32 on probe inputs: {ratio:.1e} of the output scale, threshold {PRECISION_PROBE_TOL:.0e})")
+            # printed by EVERY rank's log prefix owner (rank 0) and kept in the run's stamp: which arithmetic produced the files
+            say(f"precision: {mode} ({split} vs f32 on probe inputs: {ratio:.1e} of the output scale, threshold {PRECISION_PROBE_TOL:.0e}); "
+                "the probe is one evaluation on noise - for a run that must match the reference to its fp32 rounding, pass --precision f32")
             return mode
         if probe(model) == "f32" and args.precision == "auto":
             # bf16x3 does not hold this checkpoint to the contract: before paying 3x for the fp32 mode, try the fp16 split (22 mantissa bits per
@@ -662,7 +677,7 @@ def main(argv=None):
             args16.precision = "auto-f16x3"
             try:
                 model16 = load_model(params, args16, rank, world)
-            except (RuntimeError, SystemExit) as e:      # e.g. a weight beyond the fp16 packing's range
+            except SystemExit as e:      # e.g. a weight beyond the fp16 packing's range (load_model raises SystemExit on every rank)
                 say(f"f16x3 not available for this checkpoint ({e}); staying with f32")
                 model16 = None
             if model16 is not None and probe(model16) == "f16x3":

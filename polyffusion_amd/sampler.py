@@ -212,8 +212,9 @@ class DiffusionSampler:
 
     def _rng_ok(self, x, *others) -> bool:
         """The in-kernel noise path: on-device generator, whole Philox groups per tensor and per shard, and every tensor the
-        update kernel reads as 16-byte vectors (x and, when present, orig / orig_noise / mask) contiguous and 16-byte aligned -
-        anything else takes the randn() + step path, which has no such requirement."""
+        update kernel reads as 16-byte vectors (x and, when present, orig / orig_noise / mask) 16-byte aligned - anything else takes
+        the randn() + step path, which reads 4-byte elements.  BOTH paths read their tensors as dense buffers through raw pointers: the
+        callers (``_step``, ``repaint_step``, ``p_sample``) make every tensor contiguous before they get here."""
         per_sample = x.numel() // x.shape[0]
         if self.noise_fn is not None or x.numel() % 4 != 0 or (self.sample_offset * per_sample) % 4 != 0:
             return False
@@ -357,7 +358,7 @@ class SDFSampler(DiffusionSampler):
         ``bench.py`` times exactly this method."""
         lib, step, n = self._lib, int(step), x_t.numel()
         coef = self._coef(step)
-        x_t = x_t.contiguous()
+        x_t, orig, mask = x_t.contiguous(), orig.contiguous(), mask.contiguous()     # the update kernels read dense buffers
         e_t = self._eps(x_t, cond, step, uncond_scale, uncond_cond, cond_concat, prep)
         x = torch.empty_like(x_t)
         if step > 0 and self._rng_ok(x_t, orig, mask):
@@ -370,7 +371,6 @@ class SDFSampler(DiffusionSampler):
         # evaluation, p after it - randn() only counts draws, so drawing both here keeps the tape aligned
         noise_q = self.randn(orig.shape, x_t.device) if step > 0 else None
         noise_p = self.randn(x_t.shape, x_t.device) if step > 0 else None
-        orig, mask = orig.contiguous(), mask.contiguous()
         _lib.check(lib.pf_ddpm_step(x_t.data_ptr(), e_t.data_ptr(), _lib.ptr(noise_p), _lib.ptr(noise_q), orig.data_ptr(), mask.data_ptr(),
                                     C.byref(coef), x.data_ptr(), n, _lib.current_stream()), "pf_ddpm_step")
         return x
@@ -499,6 +499,9 @@ class DDIMSampler(DiffusionSampler):
     def _step(self, x, e_t, index, orig=None, orig_noise=None, mask=None, temperature=1.0, repeat_noise=False):
         coef = self._coef(index)
         noise = None
+        # both kernel paths below read x / e_t / orig / orig_noise / mask as dense buffers
+        x, e_t = x.contiguous(), e_t.contiguous()
+        orig, orig_noise, mask = (None if v is None else v.contiguous() for v in (orig, orig_noise, mask))
         noisy = float(self.ddim_sigma[index]) != 0.0
         if noisy and not repeat_noise and temperature == 1.0 and self._rng_ok(x, e_t, orig, orig_noise, mask):
             # the step's draw happens inside the update kernel (same values as randn() + pf_ddim_step)

@@ -174,7 +174,8 @@ class UNetModel:
         ``shared_x=True`` - classifier-free guidance (``sampler/__init__.py:69-74``): ``x`` holds B samples while ``time_steps`` and
         ``cond`` hold the 2B rows of ``cat([t, t])`` / ``cat([uncond_cond, cond])``; the result equals ``forward(cat([x, x]), ...)`` up to
         tile-choice rounding, but everything in front of the first transformer block - where the two halves cannot differ - is computed
-        once (``pf_unet_forward_cfg``).
+        once (``pf_unet_forward_cfg``).  PRECONDITION: ``time_steps[:B] == time_steps[B:]`` (the shared prefix uses the first half's rows;
+        verified under ``check_t``).
         The prepared path is valid for ``0 <= t < time_table.shape[0]`` only; ``check_t=True`` verifies that (one device->host
         sync - the samplers, whose t values are rows of a host-built table, do not ask for it)."""
         if self._blob_dev is None:
@@ -189,6 +190,10 @@ class UNetModel:
         x = x.contiguous().float()
         cond = cond.contiguous().float()
         t = time_steps.to(torch.int64).contiguous()
+        if shared_x and check_t and not torch.equal(t[: B // 2], t[B // 2:]):
+            # the shared prefix is evaluated once, with the first half's time rows: the two halves of a guidance evaluation carry the same t
+            raise RuntimeError("UNetModel.forward(shared_x=True): the two halves of time_steps must be equal "
+                               "(the conditional and unconditional evaluations share everything in front of the first transformer block)")
         n_cond = cond.shape[1]
         ws = self.workspace(B, n_cond, shared_x)
         if out is None:
@@ -238,7 +243,7 @@ class UNetModel:
         return ["f32", self._split_name][self._lib.pf_unet_get_precision(self._h)]
 
     # ---- plan options (which of two equivalent kernel forms the plan launches; include/pfhip.h PF_OPT_*) --------
-    _OPTS = {"mlp_fused": _lib.OPT_MLP_FUSED, "attn_wide": _lib.OPT_ATTN_WIDE, "conv_t16": _lib.OPT_CONV_T16, "conv_pp": _lib.OPT_CONV_PP, "pre_fused": _lib.OPT_PRE_FUSED}
+    _OPTS = {"mlp_fused": _lib.OPT_MLP_FUSED, "attn_wide": _lib.OPT_ATTN_WIDE, "conv_t16": _lib.OPT_CONV_T16, "conv_pp": _lib.OPT_CONV_PP, "pre_fused": _lib.OPT_PRE_FUSED, "conv_wino": _lib.OPT_CONV_WINO}
 
     def set_option(self, name: str, value: Optional[bool]):
         """``None`` = automatic (the default), ``False`` / ``True`` = never / always (where the form exists)."""
@@ -265,6 +270,14 @@ class UNetModel:
         fl = (C.c_double * cap)()
         n = self._check(self._lib.pf_unet_profile_read(self._h, kind, ms, fl, cap))
         return [(kind[i], ms[i], fl[i]) for i in range(n)]
+
+    def read_profile_direct(self) -> List[float]:
+        """Per launch of the last profiled forward: the operation count of the layer's DIRECT form (= read_profile()'s count except for
+        Winograd launches, which execute 16 / 36 of it)."""
+        cap = 4096
+        fl = (C.c_double * cap)()
+        n = self._check(self._lib.pf_unet_profile_read_direct(self._h, fl, cap))
+        return [fl[i] for i in range(n)]
 
     def n_launches(self, batch: int, n_cond: int = 1, prepared: bool = False, shared_x: bool = False) -> int:
         if shared_x:     # batch = the 2B rows of a guidance evaluation

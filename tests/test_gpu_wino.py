@@ -87,3 +87,90 @@ def test_wino_falls_back_when_not_eligible(lib):
     run_conv(lib, x0=x0, c0=c, batch=B, hin=H, win=W, ks=3, stride=1, ups=0, w=pack3(lib, w), n=cout, prologue=1, sc=sc, sh=sh, out=out,
              ld_out=cout, precision=1, w_wino=ww, wino=1)
     assert (out.cpu() - nhwc(ref)).abs().max() < 3e-4
+
+
+@pytest.mark.parametrize("B,H,W,c0,c1,cout,tiles", [(2, 32, 32, 256, 128, 128, 4), (1, 16, 16, 64, 32, 64, 3)])
+def test_wino_groupnorm_finalize_inside_the_consumer(lib, B, H, W, c0, c1, cout, tiles):
+    """pf_conv_args.gn_* with the Winograd form: the consumer reduces its producers' per-tile statistics itself (the rows of scale / shift
+    it writes equal pf_gn_finalize_tiles'), result against torch."""
+    cin = c0 + c1
+    x = rnd((B, cin, H, W), 51) * 1.3 + 0.2
+    w, bias = rnd((cout, cin, 3, 3), 52, (1.0 / (cin * 9)) ** 0.5), rnd((cout,), 53, 0.1)
+    gamma, beta = 1 + 0.1 * rnd((cin,), 54), 0.1 * rnd((cin,), 55)
+    ref = F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-5)), w, bias, padding=1)
+    xh = nhwc(x).reshape(B, H * W, cin)
+
+    def tile_stats(part, nt):
+        chunks = part.double().tensor_split(nt, dim=1)
+        return torch.stack([torch.stack([c.sum(1), (c * c).sum(1)], dim=-1) for c in chunks], dim=1).float().cuda().contiguous()
+
+    s0 = tile_stats(xh[..., :c0], tiles)
+    s1 = tile_stats(xh[..., c0:], tiles + 1) if c1 else None
+    g, bt = dev(gamma), dev(beta)
+    sc_ref, sh_ref = torch.empty(B, cin, device="cuda"), torch.empty(B, cin, device="cuda")
+    _lib.check(lib.pf_gn_finalize_tiles(s0.data_ptr(), tiles, c0, _lib.ptr(s1), tiles + 1 if c1 else 0, c1, B, H * W, 32, 1e-5,
+                                        g.data_ptr(), bt.data_ptr(), sc_ref.data_ptr(), sh_ref.data_ptr(), _lib.current_stream()))
+    sc, sh = torch.full((B, cin), float("nan"), device="cuda"), torch.full((B, cin), float("nan"), device="cuda")
+    out = torch.empty(B, H, W, cout, device="cuda")
+    ww = pack_wino(lib, w)
+    run_conv(lib, x0=dev(nhwc(x[:, :c0])), c0=c0, x1=dev(nhwc(x[:, c0:])) if c1 else None, c1=c1, batch=B, hin=H, win=W, ks=3, stride=1, ups=0,
+             w=pack3(lib, w), n=cout, prologue=1, bias=dev(bias), ld_out=cout, precision=1, sc=sc, sh=sh, out=out, gn_stats0=s0, gn_tiles0=tiles,
+             gn_stats1=s1 if c1 else 0, gn_tiles1=tiles + 1 if c1 else 0, gn_gamma=g, gn_beta=bt, gn_eps=1e-5, gn_groups=32, w_wino=ww, wino=1)
+    assert (sc - sc_ref).abs().max() < 1e-6 and (sh - sh_ref).abs().max() < 1e-6
+    assert (out.cpu() - nhwc(ref)).abs().max() < TOL_OP
+
+
+def _unet(x3=None):
+    import numpy as np  # noqa: F401
+    from polyffusion_amd.arch import UNetConfig
+    from polyffusion_amd.unet import UNetModel
+    from polyffusion_amd.weights import synth_unet_state
+    cfg = UNetConfig(d_cond=512)
+    kw = dict(x3=x3) if x3 else {}
+    m = UNetModel(in_channels=cfg.in_channels, out_channels=cfg.out_channels, channels=cfg.channels, n_res_blocks=cfg.n_res_blocks,
+                  attention_levels=cfg.attention_levels, channel_multipliers=cfg.channel_multipliers, n_heads=cfg.n_heads,
+                  tf_layers=cfg.tf_layers, d_cond=cfg.d_cond, img_h=128, img_w=128, **kw)
+    m.load_state_dict(synth_unet_state(cfg, 0))
+    return m
+
+
+@pytest.mark.parametrize("x3", [None, "f16"])
+def test_full_unet_with_winograd_convs_vs_reference_golden(golden, x3):
+    """Every qualifying ResBlock conv in the Winograd form (PF_OPT_CONV_WINO = on: 14 of the 22 at the 128 / 64 / 32 levels): the full UNet against
+    the REAL reference's output (tests/golden/unet_chd8bar_b2.npz), in both split builds, and bit-reproducible."""
+    import numpy as np
+    from polyffusion_amd import synth
+    g = golden("unet_chd8bar_b2.npz")
+    m = _unet(x3)
+    m.set_precision("f16x3" if x3 else "bf16x3")
+    x = torch.from_numpy(synth.gaussian((2, 2, 128, 128), int(g["x_seed"]))).cuda()
+    c = torch.from_numpy(synth.gaussian((2, 1, 512), int(g["cond_seed"]))).cuda()
+    t = torch.from_numpy(g["t"]).cuda()
+    base = m(x, t, c).cpu().numpy()
+    n0 = m.n_launches(2)
+    m.set_option("conv_wino", True)
+    o = m(x, t, c)
+    o2 = m(x, t, c)
+    assert torch.equal(o.view(torch.int32), o2.view(torch.int32))
+    o = o.cpu().numpy()
+    err, err0 = np.abs(o - g["out"]).max(), np.abs(base - g["out"]).max()
+    print(f"full UNet [{'f16x3' if x3 else 'bf16x3'}] with Winograd convs: max-abs-diff vs the reference {err:.3e} (direct form {err0:.3e}); launches {m.n_launches(2)} (direct {n0})")
+    assert np.abs(o - base).max() > 0          # the option changed the arithmetic: the form really ran
+    assert err < 1e-4, err
+
+
+def test_winograd_auto_picks_at_batch_16():
+    """AUTO (the default) at the bench's batch: the picker turns the form on for the deep-K convs; same result as the direct plan to the split's rounding."""
+    from polyffusion_amd import synth
+    m = _unet()
+    m.set_precision("bf16x3")
+    B = 16
+    x = torch.from_numpy(synth.gaussian((B, 2, 128, 128), 3)).cuda()
+    c = torch.from_numpy(synth.gaussian((B, 1, 512), 4)).cuda()
+    t = torch.full((B,), 500, dtype=torch.long, device="cuda")
+    auto = m(x, t, c)
+    m.set_option("conv_wino", False)
+    direct = m(x, t, c)
+    d = (auto - direct).abs().max().item()
+    print(f"B = 16: AUTO vs direct plan max-abs-diff {d:.3e}")
+    assert 0 < d < 1e-4
