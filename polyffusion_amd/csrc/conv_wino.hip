@@ -394,12 +394,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
   if (p.gn_s0) gn_fused_prologue<256>(p, b, tid, p.Hin * p.Win, reinterpret_cast<double*>(smem_all));
 
   // ---- halo staging: piece = (pixel, 4-channel group); a thread keeps one channel group (256 % 8 == 0) and 11 pixels.
-  // gp[i] = (pixel index + 1, 0 = outside the image) | (LDS offset in 16-byte units from 4 KB in front of the image) << 20, kept in the LDS behind the two halo images
+  // gp[i] = (pixel index within the sample + 1, 0 = outside the image) | (LDS offset in 16-byte units from 4 KB in front of the image) << 20, kept in the LDS behind the two halo images
   // ([piece][thread]: the registers are needed elsewhere) and read back one item ahead of its use
   const int sub = tid & 7;
   int* gpL = reinterpret_cast<int*>(H0 + WIMG + WHALO) + tid;
   int gpr[11];                                   // register copies for the prologue's loads
-  const int prow0 = b * p.Hin;
+  const int bpix = b * p.Hin * p.Win;            // first pixel of this sample
 #pragma unroll
   for (int it = 0; it < 11; ++it) {
     const int pix = min((tid >> 3) + 32 * it, 323);           // (the last round's surplus threads repeat pixel 323: same value, same place)
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
     const int row = (int)__umul24(pix, 57) >> 10, col = pix - (int)__umul24(row, 18);          // pix / 18 for pix < 324
     const int iy = oy0 - 1 + row, ix = ox0 - 1 + col;
     const bool inside = (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
-    const int gpix = inside ? (int)__umul24(prow0 + iy, p.Win) + ix + 1 : 0;
+    const int gpix = inside ? (int)__umul24(iy, p.Win) + ix + 1 : 0;          // within the sample (the sample's base goes into the scalar offset)
     const int real4 = (int)__umul24(row, WRP / 4) + (int)__umul24(col, WPP / 4) + (sub ^ ((row >> 1) & 1));
     const int lo4 = inside ? 256 + real4 : tid;           // in units of 16 bytes from 4 KB in front of the image
     if (!inside) {                                        // zero padding applies to the ACTIVATED tensor: written once, never overwritten
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
     const int cg = ct * 32;
     const bool first = cg < p.c0;                // wave-uniform: the source tensor of this chunk
     const __amdgpu_buffer_rsrc_t rs = dma_resource(first ? px0 : px1);
-    const int cs4 = (first ? p.c0 : p.c1) * 4, co4 = (first ? cg : cg - p.c0) * 4;
+    const int cs4 = (first ? p.c0 : p.c1) * 4, co4 = (first ? cg : cg - p.c0) * 4 + bpix * cs4;
     const int gpix = (gpv & 0xFFFFF) - 1;
     // outside the image (gpix = -1): bit 31 set - an offset >= the resource's size reads as zero, no access (branch-free)
     const int vo = ((int)__umul24(gpix, cs4) + sub * 16) | (gpix & (int)0x80000000u) | skip;
@@ -653,7 +653,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
 bool conv_wino_eligible(const pf_conv_args& a) {
   return a.wino > 0 && a.w_wino && a.precision == PF_PREC_BF16X3 && a.ks == 3 && a.stride == 1 && !a.ups && !a.ups_fold && a.prologue == 1 &&
          a.hin % 16 == 0 && a.win % 16 == 0 && a.n % 64 == 0 && a.c0 % 32 == 0 && a.c1 % 32 == 0 && !a.geglu && !a.out_planes && !a.qkv_planes &&
-         a.c0 + a.c1 <= 1024 && !a.skip_w && (a.ld_out & 3) == 0 && (!a.res || (a.ld_res & 3) == 0);
+         a.c0 + a.c1 <= 1024 && a.hin * a.win < (1 << 20) &&
+         (long long)a.batch * a.hin * a.win * (a.c0 > a.c1 ? a.c0 : a.c1) * 4 < (1ll << 31) &&      // 32-bit buffer offsets
+         (long long)a.batch * a.hin * a.win * (a.ld_out > a.ld_res ? a.ld_out : a.ld_res) * 4 < (1ll << 31) &&
+         !a.skip_w && (a.ld_out & 3) == 0 && (!a.res || (a.ld_res & 3) == 0);
 }
 
 int launch_conv_wino(const pf_conv_args& a, hipStream_t stream) {

@@ -174,3 +174,24 @@ def test_winograd_auto_picks_at_batch_16():
     d = (auto - direct).abs().max().item()
     print(f"B = 16: AUTO vs direct plan max-abs-diff {d:.3e}")
     assert 0 < d < 1e-4
+
+
+@pytest.mark.parametrize("B,shared", [(64, True), (64, False)])
+def test_winograd_large_batch_bit_reproducible(B, shared):
+    """Batch 64 (config 3's guidance evaluation: 2 x 32 rows, with and without the shared prefix): 2^20 pixels at the 128x128 level - the
+    per-piece words hold pixel indices WITHIN the sample (a 20-bit absolute index overflowed here) - every qualifying conv in the Winograd
+    form, repeated launches bit-identical, and equal to the direct plan to the split's rounding."""
+    from polyffusion_amd import synth
+    m = _unet()
+    m.set_precision("bf16x3")
+    Bx = B // 2 if shared else B
+    x = torch.from_numpy(synth.gaussian((Bx, 2, 128, 128), 3)).cuda()
+    c = torch.from_numpy(synth.gaussian((B, 1, 512), 4)).cuda()
+    t = torch.full((B,), 500, dtype=torch.long, device="cuda")
+    m.set_option("conv_wino", False)
+    direct = m(x, t, c, shared_x=shared).clone()
+    m.set_option("conv_wino", True)
+    ref = m(x, t, c, shared_x=shared).clone()
+    for _ in range(4):
+        assert torch.equal(m(x, t, c, shared_x=shared).view(torch.int32), ref.view(torch.int32))
+    assert 0 < (ref - direct).abs().max().item() < 1e-4
