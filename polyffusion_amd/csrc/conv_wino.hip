@@ -374,17 +374,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_pipe_kernel(ConvP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = row i of the transform domain
 
+  // tile decode on the scalar unit (every quantity is a function of blockIdx and launch constants; said explicitly - read-first-lane -
+  // because the compiler otherwise runs it on the vector unit and then cannot use scalar loads / scalar offsets for what depends on it)
   int lid;
   {
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    lid = __builtin_amdgcn_readfirstlane((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3));
   }
-  int mt = fdiv(lid, p.d_nt);
+  int mt = __builtin_amdgcn_readfirstlane(fdiv(lid, p.d_nt));
   const int nti = lid - mt * p.nt;
-  int t = fdiv(mt, p.d_tx);
+  int t = __builtin_amdgcn_readfirstlane(fdiv(mt, p.d_tx));
   const int tx_t = mt - t * p.tiles_x; mt = t;
-  const int b = fdiv(mt, p.d_ty);
+  const int b = __builtin_amdgcn_readfirstlane(fdiv(mt, p.d_ty));
   const int ty_t = mt - b * p.tiles_y;
   const int n0 = nti * 64, oy0 = ty_t * 16, ox0 = tx_t * 16;
   conv_shared_x1(p, b);

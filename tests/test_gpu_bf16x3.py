@@ -97,37 +97,43 @@ def test_layernorm_prologue_bf16x3(lib):
     assert (out.cpu() - ref).abs().max() < TOL_OP
 
 
-def _make(cfg, h, w):
+def _make(cfg, h, w, x3=None):
+    """x3 = None: the default split build (bf16 pieces); "f16": the fp16-piece build (libpfhip_f16.so), mode name f16x3."""
     m = UNetModel(in_channels=cfg.in_channels, out_channels=cfg.out_channels, channels=cfg.channels,
                   n_res_blocks=cfg.n_res_blocks, attention_levels=cfg.attention_levels,
                   channel_multipliers=cfg.channel_multipliers, n_heads=cfg.n_heads, tf_layers=cfg.tf_layers,
-                  d_cond=cfg.d_cond, img_h=h, img_w=w)
+                  d_cond=cfg.d_cond, img_h=h, img_w=w, **(dict(x3=x3) if x3 else {}))
     m.load_state_dict(synth_unet_state(cfg, 0))
-    return m.set_precision("bf16x3")
+    return m.set_precision(m.split_mode)
 
 
-def test_full_unet_bf16x3_meets_the_contract(golden):
+X3 = [None, "f16"]       # both split builds are covered by the driver's default run (VERDICT r5 item 3), not by an env-var re-run
+
+
+@pytest.mark.parametrize("x3", X3)
+def test_full_unet_bf16x3_meets_the_contract(golden, x3):
     """BASELINE.json: UNet output max-abs-diff < 1e-3 vs the reference on identical (x_t, t, cond)."""
     g = golden("unet_chd8bar_b2.npz")
-    m = _make(UNetConfig(d_cond=512), 128, 128)
-    assert m.precision == "bf16x3"
+    m = _make(UNetConfig(d_cond=512), 128, 128, x3)
+    assert m.precision == m.split_mode
     x = torch.from_numpy(synth.gaussian((2, 2, 128, 128), int(g["x_seed"]))).cuda()
     c = torch.from_numpy(synth.gaussian((2, 1, 512), int(g["cond_seed"]))).cuda()
     o = m(x, torch.from_numpy(g["t"]).cuda(), c).cpu().numpy()
     err = np.abs(o - g["out"]).max()
     rms = float(np.sqrt(((o - g["out"]) ** 2).mean()))
-    print(f"bf16x3 chd8bar B=2: max-abs-diff {err:.3e}, rms {rms:.3e}")
+    print(f"{m.split_mode} chd8bar B=2: max-abs-diff {err:.3e}, rms {rms:.3e}")
     assert err < 5e-4, err   # half the contract bar
     m.set_precision("f32")
     o32 = m(x, torch.from_numpy(g["t"]).cuda(), c).cpu().numpy()
     assert np.abs(o32 - g["out"]).max() < 1e-4
 
 
-def test_small_unet_bf16x3_vs_reference_golden(golden):
+@pytest.mark.parametrize("x3", X3)
+def test_small_unet_bf16x3_vs_reference_golden(golden, x3):
     SMALL = UNetConfig(in_channels=2, out_channels=2, channels=32, n_res_blocks=1, attention_levels=(1,),
                        channel_multipliers=(1, 2), n_heads=2, tf_layers=1, d_cond=32)
     g = golden("unet_small.npz")
-    m = _make(SMALL, 32, 32)
+    m = _make(SMALL, 32, 32, x3)
     x, t = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["t"]).cuda()
     assert np.abs(m(x, t, torch.from_numpy(g["cond1"]).cuda()).cpu().numpy() - g["out1"]).max() < 5e-4
     assert np.abs(m(x, t, torch.from_numpy(g["cond4"]).cuda()).cpu().numpy() - g["out4"]).max() < 5e-4
@@ -428,10 +434,11 @@ def test_full_unet_small_and_odd_batches_vs_oracle(B):
     assert err < 5e-4, err
 
 
-def test_full_unet_txt_bf16x3_vs_reference_golden(golden):
+@pytest.mark.parametrize("x3", X3)
+def test_full_unet_txt_bf16x3_vs_reference_golden(golden, x3):
     """BASELINE.json configs[3] model (sdf_txt, d_cond 1024) in the product arithmetic mode, against the reference vector."""
     g = golden("unet_txt_b1.npz")
-    m = _make(UNetConfig(d_cond=1024), 128, 128)
+    m = _make(UNetConfig(d_cond=1024), 128, 128, x3)
     x = torch.from_numpy(synth.gaussian((1, 2, 128, 128), int(g["x_seed"]))).cuda()
     c = torch.from_numpy(synth.gaussian((1, 1, 1024), int(g["cond_seed"]))).cuda()
     o = m(x, torch.from_numpy(g["t"]).cuda(), c).cpu().numpy()

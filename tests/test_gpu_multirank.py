@@ -140,3 +140,23 @@ def test_cli_two_ranks_equal_one_rank(tmp_path):
         x, y = np.load(tmp_path / "one" / a), np.load(tmp_path / "two" / b)
         assert x.shape == y.shape == (2, 2, 128, 128) and np.abs(x - y).max() < 2e-4
     assert out2.stdout.count("model_label") == 1              # only rank 0 talks
+
+
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_shard_invariance_bit_for_bit_at_equal_per_gpu_batch(tmp_path, nproc):
+    """config 4's shape - sdf_txt, 16 samples per rank - on 2 and 4 ranks (one device, gloo) against ONE process that
+    evaluates the same global batch in chunks of 16: same per-launch batch -> same tile choices -> the images are BIT-IDENTICAL
+    (tools/shard_invariance.py; weights by load_model's broadcast, noise keyed by the global sample index)."""
+    many, one = str(tmp_path / "many.npy"), str(tmp_path / "one.npy")
+    out = torchrun(["tools/shard_invariance.py", "--per_rank", "16", "--steps", "3", "--out", many], 29651 + nproc, nproc=nproc, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    env = dict(os.environ, PYTHONPATH=REPO)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    ref = subprocess.run([sys.executable, "tools/shard_invariance.py", "--chunks", str(nproc), "--per_rank", "16", "--steps", "3", "--out", one],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    assert ref.returncode == 0, ref.stdout[-2000:] + ref.stderr[-2000:]
+    a, b = np.load(many), np.load(one)
+    assert a.shape == b.shape == (16 * nproc, 2, 128, 128) and np.isfinite(a).all()
+    assert np.array_equal(a.view(np.int32), b.view(np.int32)), f"max-abs-diff {np.abs(a - b).max()}"
+    assert not np.array_equal(a[:16], a[16:32])            # different samples really are different
