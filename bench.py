@@ -671,7 +671,14 @@ def main():
             xe = sampler.randn(shape, dev)
             te = torch.full((BATCH,), 500, dtype=torch.long, device=dev)
             unet.set_precision("f32")
+            unet.track_absmax(True)      # range telemetry on the f32 evaluation: the largest |value| any layer stores (pf_unet_track_absmax)
             e32 = unet(xe, te, cond).clone()
+            am = unet.read_absmax()
+            unet.track_absmax(False)
+            f16["max_abs_activation"] = float(f"{am:.4g}")
+            f16["fp16_headroom"] = float(f"{65504.0 / am:.4g}") if am > 0 else None
+            f16["max_abs_activation_note"] = ("largest |value| stored by any layer of one evaluation of this workload (B = 16, t = 500), measured in the f32 mode; "
+                                              "f16x3's split pieces overflow beyond 65504; the CLI's --precision auto keeps f16x3 only with >= 8x headroom on its probe")
             unet.set_precision("bf16x3")
             eb, eh = unet(xe, te, cond), u16(xe, te, cond)
             sc = e32.abs().max().item()

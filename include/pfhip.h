@@ -128,6 +128,13 @@ int pf_unet_n_launches_prepared(const pf_unet* u, int batch, int n_cond, int has
 enum { PF_OPT_MLP_FUSED = 0, PF_OPT_ATTN_WIDE = 1, PF_OPT_CONV_T16 = 2, PF_OPT_CONV_PP = 3, PF_OPT_PRE_FUSED = 4, PF_OPT_CONV_WINO = 5, PF_OPT_COUNT = 6 };
 enum { PF_OPT_AUTO = -1, PF_OPT_OFF = 0, PF_OPT_ON = 1 };
 int pf_unet_set_option(pf_unet* u, int option, int value);
+/* Range telemetry.  `device_word` (4 bytes of caller-owned device memory, zeroed by the caller; NULL switches it off): while bound, every forward
+ * max-combines into it - as an fp32 bit pattern, NaN / inf kept - the largest |value| of every tensor its layers store: block outputs, the residual
+ * stream, q | k | v, GeGLU products (the fused feed-forward / pre-attention launches are replaced by their bit-identical chains while it is bound).
+ * Each of those is, after at most a normalisation, the split A operand of a following layer; the fp16-piece build (f16x3) overflows beyond 65504,
+ * so 65504 / *device_word is the run's headroom - measured in ANY arithmetic mode (in f32 nothing overflows while measuring).  inference_sdf's
+ * `--precision auto` reads it from its f32 probe before it considers f16x3; bench.py prints it (f16x3_mode.max_abs_activation). */
+int pf_unet_track_absmax(pf_unet* u, void* device_word);
 int pf_unet_get_option(const pf_unet* u, int option);
 
 /* Per-launch profiling: when enabled, forward brackets every kernel launch with hipEvents
@@ -371,6 +378,9 @@ typedef struct pf_conv_args {
    * 2.25x fewer matrix-pipe operations; equal to the direct form up to rounding (the transforms amplify the split's operand rounding
    * ~1.5x, tools/micro/winograd_numerics.py).  A launch that does not qualify runs the direct form on `w`. */
   const void* w_wino; int32_t wino;
+  /* optional range telemetry: a device word (fp32 bit pattern, start at 0) that receives max(word, largest |value| this launch stores)
+   * by atomic max - see pf_unet_track_absmax */
+  void* absmax_slot;
 } pf_conv_args;
 /* scratch bytes a launch with these arguments would like for split-K (0 = the launch does not split) */
 size_t pf_conv_splitk_ws_bytes(const pf_conv_args* a);

@@ -88,7 +88,7 @@ class ConvArgs(C.Structure):
         ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_eps", C.c_float), ("gn_groups", C.c_int32),
         ("sbias_rows", C.c_void_p), ("sbias_nrows", C.c_int32), ("no_t16", C.c_int32), ("no_pp", C.c_int32),
         ("force_tile", C.c_int32), ("force_ksplit", C.c_int32), ("x1_bmod", C.c_int32),
-        ("w_wino", C.c_void_p), ("wino", C.c_int32),
+        ("w_wino", C.c_void_p), ("wino", C.c_int32), ("absmax_slot", C.c_void_p),
     ]
 
 
@@ -121,6 +121,7 @@ SIGNATURES = {
     "pf_unet_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pf_unet_get_option": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_unet_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "pf_unet_track_absmax": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pf_unet_profile_read_direct": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
     "pf_unet_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), c_float_p, C.POINTER(C.c_double), C.c_int]),
     "pf_unet_n_launches": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

@@ -847,7 +847,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
                                                             const float* __restrict__ sbias, int ld_sb,
                                                             const long long* __restrict__ sb_rows, int sb_nrows,
                                                             const float* __restrict__ res, int ld_res, float* __restrict__ out,
-                                                            int ld_out, float* __restrict__ stats) {
+                                                            int ld_out, float* __restrict__ stats, unsigned* amax) {
   __shared__ float red[16][64][2];
   const int tid = threadIdx.x, c = tid & 63, rg = tid >> 6;   // 16 row groups x 64 columns
   const int row0 = blockIdx.x * 64;
@@ -855,6 +855,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
   {
     const int n = blockIdx.y * 64 + c;
     float s1 = 0.f, s2 = 0.f;
+    unsigned am = 0;
     if (n < N) {
       long long sr = b;
       if (sb_rows) { sr = sb_rows[b]; sr = sr < 0 ? 0 : (sr >= sb_nrows ? sb_nrows - 1 : sr); }
@@ -865,9 +866,11 @@ __global__ __launch_bounds__(1024) void splitk_reduce_kernel(const float* __rest
         for (int s = 0; s < S; ++s) v += part[((size_t)s * M + m) * N + n];
         if (res) v += res[m * ld_res + n];
         out[m * ld_out + n] = v;
+        amax_acc(am, v);
         s1 += v; s2 += v * v;
       }
     }
+    amax_flush(amax, am);
     if (stats) {
       red[rg][c][0] = s1; red[rg][c][1] = s2;
       __syncthreads();
@@ -966,6 +969,7 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   }
   p.sx0 = a.skip_x0; p.sc0 = a.skip_c0; p.sx1 = a.skip_x1; p.sc1 = a.skip_c1; p.sw = a.skip_w; p.bias2 = a.skip_w ? a.skip_bias : nullptr;
   p.x1_bmod = a.x1_bmod;
+  p.amax = static_cast<unsigned*>(a.absmax_slot);
   const int tile = conv_pick_tile(a);
   if (a.ks == 1) {
     switch (a.prologue) {
@@ -983,7 +987,7 @@ int launch_conv_bf3(const pf_conv_args& a, hipStream_t stream) {
   if (rc != PF_OK || p.ksplit == 1) return rc;
   const int M = p.B * p.Hout * p.Wout;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(M / 64, cdiv(p.N, 64)), dim3(1024), 0, stream, static_cast<const float*>(a.splitk_ws), p.ksplit, M, p.N,
-                     p.Hout * p.Wout, p.bias, p.bias2, p.sbias, p.ld_sbias, p.sb_rows, p.sb_nrows, p.res, p.ld_res, p.out, p.ld_out, p.stats);
+                     p.Hout * p.Wout, p.bias, p.bias2, p.sbias, p.ld_sbias, p.sb_rows, p.sb_nrows, p.res, p.ld_res, p.out, p.ld_out, p.stats, p.amax);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }

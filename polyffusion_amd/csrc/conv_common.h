@@ -81,6 +81,8 @@ struct ConvP {
   // tensors of the classifier-free-guidance forward, whose conditional and unconditional halves share everything computed before the first
   // transformer block (pf_unet_forward_cfg).  The kernels fold it into the base pointers once per workgroup (conv_shared_x1).
   int x1_bmod;
+  // optional range telemetry (pf_unet_track_absmax): the largest |value| this launch stores, as fp32 bits, max-combined into one device word
+  unsigned* amax;
 };
 
 // rebase the second-source pointers of this workgroup's sample (see ConvP::x1_bmod); hw_in / hw_out: pixels per sample of x1 / sx1
@@ -141,6 +143,19 @@ __device__ __forceinline__ void gn_fused_prologue(const ConvP& p, int b, int tid
   }
   __threadfence_block();
   __syncthreads();
+}
+
+// ---- range telemetry.  Every tensor a layer stores is (after at most a normalisation, which only shrinks it) the split A operand of the next
+// layer; in the fp16-piece build such an operand overflows beyond 65504.  With a slot bound (ConvP::amax / the launchers' `amax` argument) the
+// epilogues fold |v| of everything they store into a per-thread maximum - compared as unsigned bit patterns, so that a NaN (0x7fc00000) or an
+// inf is kept, not dropped - and a_max_flush combines it across the wave and into the slot with ONE atomic per wave, no return value.
+__device__ __forceinline__ void amax_acc(unsigned& m, float v) { m = max(m, __float_as_uint(v) & 0x7fffffffu); }
+__device__ __forceinline__ void amax_acc4(unsigned& m, f32x4 v) { amax_acc(m, v[0]); amax_acc(m, v[1]); amax_acc(m, v[2]); amax_acc(m, v[3]); }
+__device__ __forceinline__ void amax_flush(unsigned* slot, unsigned m) {
+  if (!slot) return;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(slot, m);
 }
 
 // x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division sequence (10 instructions shorter)
@@ -206,6 +221,7 @@ template <int TH, int TW, int BN, int FM, int FN, int NWM = 2>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][FN], int b, int oy0, int ox0, int n0,
                                               int wm, int wn, int lane, int tid, float* red, bool active = true) {
   constexpr int WM = TH * TW / NWM, WN = BN / 2;
+  unsigned am = 0;            // range telemetry (amax_acc): largest |stored value| of this thread, as bits
   // `active` == false: a wave group of the workgroup that holds no results (intra-workgroup K split, conv_bf16x3.hip) - it only
   // keeps the workgroup's barrier count in step with the active group
   if (!active) {
@@ -308,6 +324,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
       if (!cok || rl >= TH * TW || ox0 + rl >= L) continue;
       const f32x4 a = *reinterpret_cast<const f32x4*>(red + rl * pitch + col) + ra[it];
       const f32x4 c = *reinterpret_cast<const f32x4*>(red + rl * pitch + col + 4) + rc[it];
+      if (p.amax) { amax_acc4(am, a); amax_acc4(am, c); }
       // whole-vector conversions: the packed v_cvt_pk_bf16_f32 path (element-wise casts fall back to integer rounding code)
       typedef x3_t x3x4_t __attribute__((ext_vector_type(4)));
       const x3x4_t ha = __builtin_convertvector(a, x3x4_t), hc = __builtin_convertvector(c, x3x4_t);
@@ -319,6 +336,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
       *reinterpret_cast<x3x8_t*>(pq + o) = hi;
       *reinterpret_cast<x3x8_t*>(pq + pq_plane + o) = lo;
     }
+    amax_flush(p.amax, am);
     return;
   }
   if constexpr (TH == 1) if (p.qkv && (p.N / 3) % BN == 0 && n0 >= 2 * (p.N / 3) && ox0 + TW <= p.Wout) {
@@ -356,6 +374,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
       // stored positions 8c..8c+7 of this d-row: the first half of a 16-token block holds source quads 0 and 2, the second 1 and 3
       const float* src = red + cl * pitchT + (c >> 1) * 16 + (c & 1) * 4;
       const f32x4 a = *reinterpret_cast<const f32x4*>(src), q = *reinterpret_cast<const f32x4*>(src + 8);
+      if (p.amax) { amax_acc4(am, a); amax_acc4(am, q); }
       const x3x4_t ha = __builtin_convertvector(a, x3x4_t), hq = __builtin_convertvector(q, x3x4_t);
       const x3x4_t la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x4), x3x4_t);
       const x3x4_t lq = __builtin_convertvector(q - __builtin_convertvector(hq, f32x4), x3x4_t);
@@ -364,6 +383,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
       *reinterpret_cast<x3x8_t*>(base + o) = __builtin_shufflevector(ha, hq, 0, 1, 2, 3, 4, 5, 6, 7);
       *reinterpret_cast<x3x8_t*>(base + MC + o) = __builtin_shufflevector(la, lq, 0, 1, 2, 3, 4, 5, 6, 7);
     }
+    amax_flush(p.amax, am);
     return;
   }
   if constexpr (TH == 1) if (p.qkv) {
@@ -389,6 +409,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (tok0 + row >= L) continue;
             const float v = acc[fm][fn][r] + bn;
+            if (p.amax) amax_acc(am, v);
             const x3_t hi = (x3_t)v;
             ph[(size_t)row * C] = hi;
             ph[MC + (size_t)row * C] = (x3_t)(v - (float)hi);
@@ -405,6 +426,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
             f32x4 v4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v4[j] = acc[fm][fn][4 * rq + j] + bn;
+            if (p.amax) amax_acc4(am, v4);
             const x3x4_t hi4 = __builtin_convertvector(v4, x3x4_t);
             const x3x4_t lo4 = __builtin_convertvector(v4 - __builtin_convertvector(hi4, f32x4), x3x4_t);
             const size_t off = (size_t)(t0 & ~15) + qp * 4;
@@ -414,6 +436,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
         }
       }
     }
+    amax_flush(p.amax, am);
     return;
   }
   const float* sb = sbias_row(p, b);
@@ -469,10 +492,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
           v += cb4[fn];
           if (p.res) v += rr[q][fn];
           *reinterpret_cast<f32x4*>(p.out + m[q] * p.ld_out + n0 + wn * WN + fn * 32 + cq) = v;
+          if (p.amax) amax_acc4(am, v);
           s1[fn] += v; s2[fn] += v * v;
         }
       __builtin_amdgcn_sched_barrier(0);
     }
+    amax_flush(p.amax, am);
     if (p.stats) {   // workgroup-uniform
       // a lane summed its four channels over pixels j (mod 4) of one half (h): quad + half-wave reduce, then waves through LDS
 #pragma unroll
@@ -522,7 +547,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
             if (j < p.N / 2) {
               float v = acc[fm][0][r], g = acc[fm][FN - 1][r];
               if (p.bias) { v += p.bias[nv]; g += p.bias[nv + 32]; }
-              store_out(p, m * p.ld_out + j, v * gelu_erf_f(g));
+              const float o_ = v * gelu_erf_f(g);
+              if (p.amax) amax_acc(am, o_);
+              store_out(p, m * p.ld_out + j, o_);
             }
           }
         } else {
@@ -536,6 +563,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
               if (p.bias2) v += p.bias2[n];
               if (p.res) v += p.res[m * p.ld_res + n];
               store_out(p, m * p.ld_out + n, v);
+              if (p.amax) amax_acc(am, v);
               ssum[fn] += v; ssq[fn] += v * v;
             }
           }
@@ -544,6 +572,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[FM][
     }
   }
 
+  amax_flush(p.amax, am);
   if (p.stats) {   // workgroup-uniform
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn) { ssum[fn] += __shfl_xor(ssum[fn], 32); ssq[fn] += __shfl_xor(ssq[fn], 32); }

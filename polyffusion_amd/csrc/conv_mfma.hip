@@ -384,6 +384,7 @@ int launch_conv(const pf_conv_args& a, hipStream_t stream) {
   p.sb_rows = reinterpret_cast<const long long*>(a.sbias_rows); p.sb_nrows = a.sbias_nrows;
   p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out;
   p.ksplit = 1; p.partial = nullptr; p.qkv = a.qkv_planes; p.out_planes = a.out_planes;
+  p.amax = static_cast<unsigned*>(a.absmax_slot);
 
   const int tile = conv_pick_tile(a);
 

@@ -126,6 +126,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvP& p, f32x16 (&acc)[4][2
   // Y[0][q] = S0 + S1 + S2, Y[1][q] = S1 - S2 - S3
   const f32x4 cb4 = cba + cbb + cbc;
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  unsigned am = 0;
   const float* Xr = X + (tl & 3) * 64 + ((tl >> 2) & 1) * 32 + c8 * 4;
 #pragma unroll
   for (int u = 0; u < 4; ++u)
@@ -139,10 +140,12 @@ __device__ __forceinline__ void wino_epilogue(const ConvP& p, f32x16 (&acc)[4][2
         f32x4 v = pp == 0 ? sv[0] + sv[1] + sv[2] : sv[1] - sv[2] - sv[3];
         v = PF_X3_UNSCALE(v) + cb4 + rr[u][pp][q];
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsOut, (pix(u, pp, q) * p.ld_out + n) * 4, 0, 0);
+        if (p.amax) amax_acc4(am, v);
         s1 += v; s2 += v * v;
       }
     }
   WTR();
+  amax_flush(p.amax, am);
   if (p.stats) {   // workgroup-uniform
     // a lane summed its four channels over the 16 pixels of its tile column; the 16 partial sums of a channel (8 tile columns x 2 tile
     // halves) meet in the LDS and are added in a fixed order by the channel's thread (cross-lane shuffles cost a round trip each here)
@@ -677,6 +680,7 @@ int launch_conv_wino(const pf_conv_args& a, hipStream_t stream) {
     p.gn_gamma = a.gn_gamma; p.gn_beta = a.gn_beta; p.gn_eps = a.gn_eps; p.gn_groups = a.gn_groups;
   }
   p.x1_bmod = a.x1_bmod;
+  p.amax = static_cast<unsigned*>(a.absmax_slot);
   p.tiles_x = a.win / 16; p.tiles_y = a.hin / 16; p.nt = a.n / 64;
   conv_fill_divs(p);
   const int grid = p.B * p.tiles_y * p.tiles_x * p.nt;

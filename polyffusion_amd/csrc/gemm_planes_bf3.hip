@@ -198,6 +198,7 @@ int launch_gemm_planes(const pf_conv_args& a, hipStream_t stream) {
   p.sb_rows = reinterpret_cast<const long long*>(a.sbias_rows); p.sb_nrows = a.sbias_nrows;
   p.geglu = a.geglu; p.out = a.out; p.ld_out = a.ld_out; p.stats = a.stats_out; p.out_planes = a.out_planes; p.qkv = a.qkv_planes;
   p.ksplit = 1;
+  p.amax = static_cast<unsigned*>(a.absmax_slot);
   const int tile = conv_pick_tile(a);
   // ring depth: the deepest that still lets two workgroups share a CU's 160 KB (a 128x128 stage is 32 KB)
   if (tile == 0) return launch_gp<128, 128, 2>(p, stream);

@@ -70,6 +70,7 @@ struct pf_unet {
   int cross_cursor = 0;
   size_t cross_o_cursor = 0;
   const float* wdev = nullptr;
+  void* amax_slot = nullptr;    // pf_unet_track_absmax: caller-owned device word, nullptr = off
   int opt[PF_OPT_COUNT] = {PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO};   // pf_unet_set_option
   // profiling
   int precision = PF_PREC_F32;
@@ -434,6 +435,7 @@ struct Ctx {
     const int cin_ = a.c0 + a.c1;
     const bool bf3 = u->precision == PF_PREC_BF16X3 && cin_ % 32 == 0;
     if (bf3) a.precision = PF_PREC_BF16X3;   // decided before the tile (and thus the statistics layout) is chosen
+    a.absmax_slot = u->amax_slot;
     a.no_t16 = u->opt[PF_OPT_CONV_T16] == PF_OPT_OFF;
     a.no_pp = u->opt[PF_OPT_CONV_PP] == PF_OPT_OFF;
     if (const size_t wsb = conv_splitk_ws_bytes(a)) {   // small-M layer: K-split partial sums live in the temp region
@@ -617,7 +619,7 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
   // bf16x3 mode, d_head 64, L % 128 == 0: every linear layer of the block runs on pre-split hi/lo planes (see the loop below)
   const bool planes_ok = c.u->precision == PF_PREC_BF16X3 && dh == 64 && hw % 128 == 0 && C % 32 == 0 && C <= 1024;
   // ... and for d_model 256 the whole pre-attention half of the first layer - this GroupNorm, proj_in, LayerNorm1, q|k|v - is one launch
-  const bool pre_fused = planes_ok && !L.tbs.empty() && preattn_fused_wanted(C, hw, M, c.u->opt[PF_OPT_PRE_FUSED]);
+  const bool pre_fused = planes_ok && !L.tbs.empty() && preattn_fused_wanted(C, hw, M, c.u->opt[PF_OPT_PRE_FUSED]) && !c.u->amax_slot;   // (range telemetry runs the chains: their epilogues carry it)
   if (pre_fused) {
     const Layer::TB& t = L.tbs[0];
     c.prof_begin(PF_K_GEMM, 2.0 * M * ((double)C * C + 3.0 * C * C));
@@ -666,7 +668,7 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
                     : launch_attention(qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, att, C, B, nh, dh, hw, hw, c.s);
     c.prof_end();
     last_planes = planes && (i + 1 == L.tbs.size());
-    const bool fuse_mlp = planes && mlp_fused_wanted(C, hw, M, c.u->opt[PF_OPT_MLP_FUSED]);
+    const bool fuse_mlp = planes && mlp_fused_wanted(C, hw, M, c.u->opt[PF_OPT_MLP_FUSED]) && !c.u->amax_slot;
     {
       pf_conv_args a = conv_base(att, C, nullptr, 0, B, 1, hw, 1, c.w(t.o1w), C, t1);
       a.bias = c.w(t.o1b); a.res = t0; a.ld_res = C; a.a_planes = planes ? 1 : 0;
@@ -1097,6 +1099,11 @@ int pf_unet_n_launches_prepared(const pf_unet* u, int batch, int n_cond, int has
 int pf_unet_set_option(pf_unet* u, int option, int value) {
   PF_REQUIRE(u && option >= 0 && option < PF_OPT_COUNT && value >= PF_OPT_AUTO && value <= PF_OPT_ON, "pf_unet_set_option: bad arguments");
   u->opt[option] = value;
+  return PF_OK;
+}
+int pf_unet_track_absmax(pf_unet* u, void* device_word) {
+  PF_REQUIRE(u, "null handle");
+  u->amax_slot = device_word;
   return PF_OK;
 }
 int pf_unet_get_option(const pf_unet* u, int option) { return (u && option >= 0 && option < PF_OPT_COUNT) ? u->opt[option] : -2; }

@@ -240,6 +240,7 @@ def build_unet(params, device=None, x3=None) -> UNetModel:
 
 
 PRECISION_PROBE_TOL = 3e-4
+F16_HEADROOM_MIN = 8.0       # f16x3 is kept only if 65504 / max|stored activation| on the probe is at least this
 
 
 def pick_precision(unet: UNetModel, cond: torch.Tensor, tol: Optional[float] = None, n_steps: int = 1000, seed: int = 0):
@@ -258,14 +259,26 @@ def pick_precision(unet: UNetModel, cond: torch.Tensor, tol: Optional[float] = N
     t = torch.tensor([n_steps - 1, n_steps // 2, 0], device=cond.device)
     c = cond[torch.arange(n, device=cond.device) % cond.shape[0]].contiguous()
     unet.set_precision("f32")
+    # the f32 evaluation doubles as the range measurement: the largest |value| any layer stores (pf_unet_track_absmax).  In the fp16-piece
+    # build such a value overflows beyond 65504; measured in f32 nothing overflows while measuring.  A model of the fp16 build must show
+    # F16_HEADROOM_MIN x headroom on the probe to be kept in f16x3 - the probe inputs are three samples, a loop sees a thousand.
+    unet.track_absmax(True)
     ref = unet(x, t, c).clone()
-    unet.set_precision(unet.split_mode)     # "bf16x3", or "f16x3" for a model built in the fp16-split library (where the probe mostly
-    got = unet(x, t, c)                     # guards fp16's range: an activation beyond 65504 shows up as a non-finite result)
+    absmax = unet.read_absmax()
+    unet.track_absmax(False)
+    pick_precision.last_absmax = absmax
+    unet.set_precision(unet.split_mode)     # "bf16x3", or "f16x3" for a model built in the fp16-split library
+    got = unet(x, t, c)
     scale = ref.abs().max().item()
     ratio = float("inf") if not (scale > 0 and bool(torch.isfinite(got).all())) else (got - ref).abs().max().item() / scale
+    if unet.split_mode == "f16x3" and not (absmax * F16_HEADROOM_MIN <= 65504.0):
+        ratio = float("inf")                # too close to fp16's range (or already beyond it: nan / inf compare false)
     mode = unet.split_mode if ratio <= tol else "f32"
     unet.set_precision(mode)
     return mode, ratio
+
+
+pick_precision.last_absmax = float("nan")
 
 
 def build_ldm(params, unet: UNetModel) -> LatentDiffusion:
@@ -666,7 +679,10 @@ def main(argv=None):
             mode = ["f32", split][pfdist.broadcast_int(int(mode == split))]        # one decision for all ranks (rank 0's)
             mdl.ldm.eps_model.set_precision(mode)
             # printed by EVERY rank's log prefix owner (rank 0) and kept in the run's stamp: which arithmetic produced the files
-            say(f"precision: {mode} ({split} vs f32 on probe inputs: {ratio:.1e} of the output scale, threshold {PRECISION_PROBE_TOL:.0e}); "
+            am = pick_precision.last_absmax
+            say(f"precision: {mode} ({split} vs f32 on probe inputs: {ratio:.1e} of the output scale, threshold {PRECISION_PROBE_TOL:.0e}; "
+                f"largest |activation| stored on the probe {am:.3g} = fp16 headroom x{65504.0 / am if am > 0 else float('inf'):.0f}"
+                f"{', f16x3 needs x%g' % F16_HEADROOM_MIN if split == 'f16x3' else ''}); "
                 "the probe is one evaluation on noise - for a run that must match the reference to its fp32 rounding, pass --precision f32")
             return mode
         if probe(model) == "f32" and args.precision == "auto":

@@ -56,6 +56,7 @@ class UNetModel:
         self._blob_host: Optional[torch.Tensor] = None
         self._blob_dev: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
+        self._amax: Optional[torch.Tensor] = None      # range telemetry word (track_absmax)
         self._ws_key = (0, 0, 0)
 
     def _check(self, rc: int, what: str = "") -> int:
@@ -257,7 +258,22 @@ class UNetModel:
 
     def options_key(self) -> tuple:
         """Every plan option's current setting: part of the key of anything that bakes the launch sequence in (workspace, graphs)."""
-        return tuple(self._lib.pf_unet_get_option(self._h, o) for o in range(_lib.OPT_COUNT))
+        return tuple(self._lib.pf_unet_get_option(self._h, o) for o in range(_lib.OPT_COUNT)) + (self._amax is not None,)
+
+    # ---- range telemetry (include/pfhip.h pf_unet_track_absmax) -----------------------------------
+    def track_absmax(self, on: bool = True):
+        """While on, every forward max-combines the largest |value| its layers store into one device word (reset here)."""
+        dev = self._blob_dev.device if self._blob_dev is not None else torch.device("cuda")
+        self._amax = torch.zeros(1, dtype=torch.int32, device=dev) if on else None
+        self._check(self._lib.pf_unet_track_absmax(self._h, None if self._amax is None else self._amax.data_ptr()), "pf_unet_track_absmax")
+        self._ws = None          # the plan changes (fused launches run as their chains while tracking)
+        return self
+
+    def read_absmax(self) -> float:
+        """Largest |stored value| since track_absmax(True) (nan / inf if one was stored); 65504 / it = the fp16 split's headroom."""
+        if self._amax is None:
+            raise RuntimeError("read_absmax: telemetry is off (track_absmax(True) first)")
+        return float(self._amax.view(torch.float32).item())
 
     # ---- profiling ------------------------------------------------------------------------------
     def set_profiling(self, on: bool):

@@ -241,3 +241,62 @@ def test_cli_refuses_non_finite_results(tmp_path):
     with pytest.raises(SystemExit, match="non-finite.*f16x3 overflows"):
         inference_sdf.main(base + ["--output_dir", str(tmp_path / "h"), "--precision", "f16x3"])
     assert not os.path.exists(tmp_path / "h") or not os.listdir(tmp_path / "h")
+
+
+def test_range_telemetry_measures_what_the_layers_store():
+    """pf_unet_track_absmax: (1) one pf_conv2d launch reports exactly max|out| of what it stored; (2) a full forward reports a modest number on
+    the synthetic weights - the same in the f32 and the split modes, up to their rounding - and the headroom 65504 / it; (3) on the net whose
+    residual stream is driven beyond fp16's range (the construction of the overflow test above) the f32 measurement says so BEFORE f16x3 is
+    tried: pick_precision refuses f16x3 without evaluating into an overflow."""
+    import ctypes as C
+    from polyffusion_amd import _lib
+    from test_gpu_ops import dev, nhwc, rnd, run_conv, gn_scale_shift, pack_w
+    from test_gpu_bf16x3 import pack3
+    import torch.nn.functional as F
+    lib = _lib.load()
+    B, H, W, c, cout = 2, 32, 32, 64, 64
+    x = rnd((B, c, H, W), 1) * 3.0
+    w = rnd((cout, c, 3, 3), 2, (1.0 / (c * 9)) ** 0.5)
+    gamma, beta = 1 + 0.1 * rnd((c,), 4), 0.1 * rnd((c,), 5)
+    x0 = dev(nhwc(x))
+    sc, sh = gn_scale_shift(lib, x0, None, dev(gamma), dev(beta), 1e-5)
+    for prec in (0, 1):
+        out = torch.empty(B, H, W, cout, device="cuda")
+        slot = torch.zeros(1, dtype=torch.int32, device="cuda")
+        run_conv(lib, x0=x0, c0=c, batch=B, hin=H, win=W, ks=3, stride=1, ups=0, w=pack3(lib, w) if prec else pack_w(lib, w), n=cout, prologue=1,
+                 sc=sc, sh=sh, out=out, ld_out=cout, precision=prec, absmax_slot=slot)
+        assert slot.view(torch.float32).item() == out.abs().max().item()
+    cfg = UNetConfig(d_cond=512)
+    m = build_unet(preset("sdf_chd8bar"))
+    m.load_state_dict(synth_unet_state(cfg, 0))
+    xx = torch.from_numpy(synth.gaussian((2, 2, 128, 128), 7)).cuda()
+    cc = torch.from_numpy(synth.gaussian((2, 1, 512), 8)).cuda()
+    tt = torch.tensor([999, 3]).cuda()
+    vals = {}
+    for mode in ("f32", "bf16x3"):
+        m.set_precision(mode)
+        base = m(xx, tt, cc).clone()
+        m.track_absmax(True)
+        tracked = m(xx, tt, cc)
+        vals[mode] = m.read_absmax()
+        m.track_absmax(False)
+        assert (tracked - base).abs().max().item() < 1e-5          # the tracked plan (chains instead of fused launches) computes the same thing
+    print("max |stored activation|, synthetic weights:", vals, "fp16 headroom x%.0f" % (65504 / vals["f32"]))
+    assert 1.0 < vals["f32"] < 8000 and abs(vals["f32"] - vals["bf16x3"]) < 1e-3 * vals["f32"]
+    # (3) the overflow construction: the f32 probe SEES the 2e5 before the fp16 build is asked to evaluate it
+    p = preset("sdf_chd8bar")
+    st = synth_unet_state(cfg, 0)
+    key = next(k for k in st if k.endswith("proj_in.weight"))
+    gain = key.replace("proj_in.weight", "norm.weight")
+    st[key] = (st[key] * np.float32(100)).astype(np.float32)
+    st[gain] = (st[gain] * np.float32(2000)).astype(np.float32)
+    u16 = build_unet(p, x3="f16")
+    u16.load_state_dict(st)
+    c3 = torch.from_numpy(synth.gaussian((3, 1, p.d_cond), 9)).cuda()
+    mode16, ratio16 = pick_precision(u16, c3)
+    am = pick_precision.last_absmax
+    print(f"overflow net: largest |stored activation| on the f32 probe {am:.3g}")
+    assert mode16 == "f32" and am > 65504
+    u16.load_state_dict(synth_unet_state(cfg, 0))
+    mode16, _ = pick_precision(u16, c3)
+    assert mode16 == "f16x3" and 65504 / pick_precision.last_absmax >= 8
