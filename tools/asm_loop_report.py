@@ -10,7 +10,7 @@ name = sys.argv[2]
 m = re.search(r"^(\S*%s\S*):" % re.escape(name), s, re.M)
 k = m.start()
 body = s[k:s.index(".Lfunc_end", k)].split("\n")
-mf = [i for i, l in enumerate(body) if "v_mfma" in l]
+mf = [i for i, l in enumerate(body) if "v_mfma" in l and not l.rstrip().endswith(", 0")]   # (not the accumulator-clearing ones)
 print(m.group(1), "lines", len(body), "mfma", len(mf), "first", mf[0], "last", mf[-1])
 reg = body[mf[0] - 60:mf[-1] + 5]
 c = collections.Counter()
