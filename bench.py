@@ -108,9 +108,10 @@ def cpu_baseline(params, reps=3):
         return time.perf_counter() - t0
 
     default_threads = torch.get_num_threads()
-    # oneDNN's convolutions stop scaling long before a 256-thread host is full (measured on the GPU box: 32 threads 0.31 steps/s,
-    # 64: 0.20, 128: 0.11, all 256: 0.008), so the sweep stays at or below 128 and the best count is what gets reported
-    sweep = sorted({n for n in (16, 32, 64, 128) if n <= ncpu}) or [ncpu]
+    # oneDNN's convolutions stop scaling long before a 256-thread host is full (measured on the GPU boxes in rounds 3-6, every run: 16 threads
+    # 0.28, 32: 0.29-0.33, 64: 0.20-0.21, 128: 0.10-0.11, all 256: 0.008 steps/s), so the sweep probes 16 and 32 only - the two larger counts
+    # cost 30 s of a default run to confirm that they lose - and the best count is what gets reported (the whole leg: ~25 s of CPU work)
+    sweep = sorted({n for n in (16, 32) if n <= ncpu}) or [ncpu]
     probes = {}
     with torch.no_grad():
         torch.set_num_threads(min(32, ncpu))

@@ -12,6 +12,7 @@ from polyffusion_amd import _lib
 #   mode 1: A operand as pre-split bf16 hi/lo planes   2: GeGLU product out as planes   3: q|k|v planes out
 #        4: planes in, planes out (+ residual)          5: planes out, no residual       6: fp32 out, no residual
 #        7: second conv of a channel-changing ResBlock, the 1x1 skip projection of concat(x, skip) fused in
+#        8: the fused Winograd F(2x2, 3x3) form of the ResBlock conv (pf_conv_args.wino, csrc/conv_wino.hip)
 SHAPES = [
     ("r128_64_64", 16, 128, 128, 64, 0, 64, 3, 1, 0, 1),
     ("r128_128+64_64", 16, 128, 128, 128, 64, 64, 3, 1, 0, 1),
@@ -26,6 +27,11 @@ SHAPES = [
     ("rs128_64_64", 16, 128, 128, 64, 0, 64, 3, 1, 0, 1, 7, 128, 64),
     ("rs64_128_128", 16, 64, 64, 128, 0, 128, 3, 1, 0, 1, 7, 256, 128),
     ("rs32_256_256", 16, 32, 32, 256, 0, 256, 3, 1, 0, 1, 7, 256, 256),
+    ("w128_64_64", 16, 128, 128, 64, 0, 64, 3, 1, 0, 1, 8),
+    ("w128_128+64_64", 16, 128, 128, 128, 64, 64, 3, 1, 0, 1, 8),
+    ("w64_256+128_128", 16, 64, 64, 256, 128, 128, 3, 1, 0, 1, 8),
+    ("w32_256_256", 16, 32, 32, 256, 0, 256, 3, 1, 0, 1, 8),
+    ("w32_256+256_256", 16, 32, 32, 256, 256, 256, 3, 1, 0, 1, 8),
     ("g1024_256_256", 16, 1, 1024, 256, 0, 256, 1, 1, 0, 0),
     ("g1024_256_768ln", 16, 1, 1024, 256, 0, 768, 1, 1, 0, 3),
     ("g1024_1024_256", 16, 1, 1024, 1024, 0, 256, 1, 1, 0, 0),
@@ -53,7 +59,7 @@ def shape_mode(shape) -> int:
 def supported(shape, prec: int) -> bool:
     """Plane operands / outputs and the fused skip projection exist only in the bf16x3 mode (pf_conv2d answers PF_EINVAL
     for them in f32 mode, as the header says)."""
-    return prec == 1 or shape_mode(shape) == 0
+    return prec == 1 or shape_mode(shape) in (0, 8)     # (8: pf_conv_args.wino in f32 mode runs the direct form - nothing to refuse)
 
 
 class Launch:
@@ -83,7 +89,7 @@ class Launch:
         a.sc, a.sh, a.mean, a.rstd = sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), rstd.data_ptr()
         a.bias, a.res, a.ld_res = bias.data_ptr(), res.data_ptr(), n
         a.out, a.ld_out, a.precision = out.data_ptr(), n, prec
-        a.a_planes = int(mode not in (0, 7))   # same bytes as fp32 [M][K]: random bits are fine for timing / reproducibility
+        a.a_planes = int(mode not in (0, 7, 8))   # same bytes as fp32 [M][K]: random bits are fine for timing / reproducibility
         self.keep = [x0, x1, w, sc, sh, mean, rstd, bias, res]
         if mode == 2:
             a.geglu, a.ld_out, a.out_planes, a.res = 1, n // 2, out.data_ptr(), 0
@@ -94,6 +100,10 @@ class Launch:
         if mode == 3:
             a.qkv_planes, a.res = out.data_ptr(), 0
         skip_k = 0
+        if mode == 8:
+            ww = torch.randint(0, 2 ** 15, (lib.pf_wino_weight_bytes(n, cin) // 2,), device="cuda", dtype=torch.int16, generator=g)   # finite pieces
+            a.w_wino, a.wino = ww.data_ptr(), 1
+            self.keep.append(ww)
         if mode == 7:
             sc0, sc1 = rest[1], rest[2]
             sx0 = rn(B, H, W, sc0); sx1 = rn(B, H, W, sc1)

@@ -221,3 +221,47 @@ if r == 0: print("OK", got)
                           "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
                          capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_winograd_weight_packing_reproduces_the_convolution(lib):
+    """pf_pack_wino_weight_bf16x3 on the host: U = G g G^T per (n, k), split into hi | lo pieces, laid out [i][K/16][N/64][j][nb][plane][lane][8]
+    (csrc/conv_wino.hip).  Unpacked again here and used in a numpy Winograd F(2x2, 3x3) evaluation, the packing must reproduce a plain 3x3
+    correlation (ref: stable_diffusion/model/unet.py:262-318 convs) to the split's 16-bit-mantissa accuracy - layout AND transform."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    N, K, H, W = 64, 32, 8, 8
+    w = (rng.standard_normal((N, K, 3, 3)) * 0.1).astype(np.float32)
+    x = rng.standard_normal((K, H + 2, W + 2)).astype(np.float32)           # already padded input
+    assert lib.pf_wino_weight_bytes(N, K) == 16 * K * N * 4
+    dst = np.zeros(16 * K * N * 2, dtype=np.uint16)
+    assert lib.pf_pack_wino_weight_bf16x3(w.ctypes.data, N, K, dst.ctypes.data) == 0
+    assert lib.pf_pack_wino_weight_bf16x3(w.ctypes.data, 48, K, dst.ctypes.data) != 0     # n must be a multiple of 64
+    d = dst.reshape(4, K // 16, N // 64, 4, 2, 2, 64, 8)                     # [i][kk][ntile][j][nb][plane][lane][e]
+    if lib.pf_x3_element() == 0:
+        piece = lambda u: (u.astype(np.uint32) << 16).view(np.float32)      # bf16 -> fp32
+        scale = 1.0
+    else:
+        piece = lambda u: u.view(np.float16).astype(np.float32)
+        scale = 1.0 / 256.0
+    U = np.zeros((4, 4, K, N), np.float64)
+    for kk in range(K // 16):
+        for nb in range(2):
+            for lane in range(64):
+                for e in range(8):
+                    k, n = kk * 16 + (lane >> 5) * 8 + e, nb * 32 + (lane & 31)
+                    U[:, :, k, n] = (piece(d[:, kk, 0, :, nb, 0, lane, e]).astype(np.float64) + piece(d[:, kk, 0, :, nb, 1, lane, e])) * scale
+    Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+    At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+    out = np.zeros((N, H, W))
+    for ty in range(H // 2):
+        for tx in range(W // 2):
+            dd = x[:, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4].astype(np.float64)          # [K,4,4]
+            V = np.einsum("ia,kab,jb->ijk", Bt, dd, Bt)
+            M = np.einsum("ijk,ijkn->ijn", V, U)
+            out[:, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum("pi,ijn,qj->npq", At, M, At)
+    ref = np.zeros((N, H, W))
+    for ky in range(3):
+        for kx in range(3):
+            ref += np.einsum("nk,khw->nhw", w[:, :, ky, kx].astype(np.float64), x[:, ky:ky + H, kx:kx + W].astype(np.float64))
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    assert err < 2e-5, err
