@@ -119,13 +119,10 @@ int pf_unet_n_launches_prepared(const pf_unet* u, int batch, int n_cond, int has
  *   PF_OPT_CONV_T16   - 16x16-pixel tile for the 64-output-channel 3x3 convs with >= 128 input channels vs the 8x16 tile
  *   PF_OPT_CONV_PP    - 3x3 convs whose 128-wide tiles give every CU at most one workgroup (B = 16: the 32x32 level) as 8-wave workgroups:
  *                       two wave groups split K and run half a tap apart, one loading while the other computes (equal up to summation order)
- *   PF_OPT_PRE_FUSED  - the pre-attention half of a SpatialTransformer's first layer (GroupNorm + proj_in + LayerNorm1 + q|k|v projection,
- *                       pf_preattn_fused) as ONE launch per 64-token tile vs three launches; equal up to summation order; auto = off
- *                       (measured neutral end to end, profiles/r05_ab_pre_fused.md); on: every block with d_model 256 and L % 64 == 0
  *   PF_OPT_CONV_WINO  - ResBlock 3x3 convs in the fused Winograd F(2x2, 3x3) form (pf_conv_args.wino; bf16x3 / f16x3 modes; equal to the direct
  *                       form up to rounding, 2.25x fewer matrix operations) vs the direct implicit GEMM; auto: where it measured faster
  *                       (profiles/r06_ab_winograd.md: input channels >= 192, or >= 128 at 32x32 and below); on: every conv that qualifies */
-enum { PF_OPT_MLP_FUSED = 0, PF_OPT_ATTN_WIDE = 1, PF_OPT_CONV_T16 = 2, PF_OPT_CONV_PP = 3, PF_OPT_PRE_FUSED = 4, PF_OPT_CONV_WINO = 5, PF_OPT_COUNT = 6 };
+enum { PF_OPT_MLP_FUSED = 0, PF_OPT_ATTN_WIDE = 1, PF_OPT_CONV_T16 = 2, PF_OPT_CONV_PP = 3, PF_OPT_CONV_WINO = 4, PF_OPT_COUNT = 5 };
 enum { PF_OPT_AUTO = -1, PF_OPT_OFF = 0, PF_OPT_ON = 1 };
 int pf_unet_set_option(pf_unet* u, int option, int value);
 /* Range telemetry.  `device_word` (4 bytes of caller-owned device memory, zeroed by the caller; NULL switches it off): while bound, every forward
@@ -310,18 +307,6 @@ int pf_mlp_geglu_fused(const float* x, int batch, int l, const float* ln_gamma, 
 int pf_mlp_geglu_proj_fused(const float* x, int batch, int l, const float* ln_gamma, const float* ln_beta, float ln_eps,
                             const void* w1_bf16x3, const float* b1, const void* w2_bf16x3, const float* b2,
                             const void* w3_bf16x3, const float* b3, const float* res3, float* out, float* stats3, void* stream);
-/* The pre-attention half of a SpatialTransformer's first transformer layer as ONE launch (unet_attention.py:64-72 `norm`, `proj_in`, the
- * NCHW -> token permute; :240-243 `attn1(norm1(x))` up to the three projections of CrossAttention :150-166) for d_model 256, bf16x3 arithmetic:
- *   y = W_in . (x * sc[b] + sh[b]) + b_in;   q|k|v = W_qkv . LayerNorm1(y)
- * x fp32 [batch*l][256] (NHWC rows), l % 64 == 0; sc / sh [batch][256]: GroupNorm scale / shift (pf_gn_finalize_tiles' output), or - when
- * gn_stats != NULL: the producer's per-tile statistics [batch][gn_tiles][256][2] - written by this launch itself (32 groups, gn_gamma /
- * gn_beta / gn_eps); w_in_bf16x3 / w_qkv_bf16x3: pf_pack_gemm_weight_bf16x3 of proj_in ([256][256]) and of the row-concatenated
- * to_q | to_k | to_v ([768][256]); y: fp32 [batch*l][256] (the residual stream attn1.to_out adds back); qkv_planes: as pf_conv_args.qkv_planes.
- * Equals pf_conv2d(prologue 2) + pf_ln_planes + pf_conv2d(a_planes, qkv_planes) up to the summation order inside proj_in. */
-int pf_preattn_fused(const float* x, int batch, int l, float* sc, float* sh, const float* gn_stats, int gn_tiles, const float* gn_gamma,
-                     const float* gn_beta, float gn_eps, const void* w_in_bf16x3, const float* b_in, float* y, const float* ln_gamma,
-                     const float* ln_beta, float ln_eps, const void* w_qkv_bf16x3, void* qkv_planes, void* stream);
-
 /* Implicit-GEMM convolution / linear on NHWC with fused prologue and epilogue (fp32 MFMA).
  *   ks 1|3, stride 1|2, ups 0|1 (nearest x2 folded into the input read, unet.py:236-238)
  *   prologue: 0 none | 1 y=silu(x*sc+sh) | 2 y=x*sc+sh (sc,sh [B][Cin]) | 3 LayerNorm (mean,rstd per row; sc,sh = gamma,beta [Cin])

@@ -61,8 +61,8 @@ class UNetPrepared(C.Structure):
     _fields_ = [("time_table", C.c_void_p), ("n_time_rows", C.c_int32), ("cross_bias", C.c_void_p)]
 
 
-OPT_MLP_FUSED, OPT_ATTN_WIDE, OPT_CONV_T16, OPT_CONV_PP, OPT_PRE_FUSED, OPT_CONV_WINO = 0, 1, 2, 3, 4, 5
-OPT_COUNT = 6              # PF_OPT_COUNT
+OPT_MLP_FUSED, OPT_ATTN_WIDE, OPT_CONV_T16, OPT_CONV_PP, OPT_CONV_WINO = 0, 1, 2, 3, 4
+OPT_COUNT = 5              # PF_OPT_COUNT
 OPT_AUTO, OPT_OFF, OPT_ON = -1, 0, 1
 
 
@@ -170,8 +170,6 @@ SIGNATURES = {
     "pf_ln_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_mlp_geglu_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "pf_preattn_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_mlp_geglu_proj_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 10),
     "pf_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "pf_conv_stats_tiles": (C.c_int, [C.POINTER(ConvArgs)]),

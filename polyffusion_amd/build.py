@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["conv_mfma.hip", "conv_bf16x3.hip", "conv_wino.hip", "gemm_planes_bf3.hip", "mlp_fused_bf3.hip", "preattn_fused_bf3.hip", "attention.hip", "attention_bf3.hip", "norm_stats.hip", "small_kernels.hip", "encoders.hip", "comm.hip", "unet.hip"]
+SOURCES = ["conv_mfma.hip", "conv_bf16x3.hip", "conv_wino.hip", "gemm_planes_bf3.hip", "mlp_fused_bf3.hip", "attention.hip", "attention_bf3.hip", "norm_stats.hip", "small_kernels.hip", "encoders.hip", "comm.hip", "unet.hip"]
 LIB = os.path.join(HERE, "libpfhip.so")
 # variants: the same sources compiled with another element type for the split-precision kernels (csrc/pf_internal.h, PF_X3_F16);
 # objects get a suffix, the library another name, the stamp its own keys.  PF_X3=f16 in the environment selects it at load (_lib.py).
@@ -63,7 +63,7 @@ def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
 
 
 # slowest translation units first, so that the pool's tail is short
-_SLOW_FIRST = ["conv_bf16x3.hip", "conv_wino.hip", "attention_bf3.hip", "mlp_fused_bf3.hip", "preattn_fused_bf3.hip", "conv_mfma.hip", "gemm_planes_bf3.hip"]
+_SLOW_FIRST = ["conv_bf16x3.hip", "conv_wino.hip", "attention_bf3.hip", "mlp_fused_bf3.hip", "conv_mfma.hip", "gemm_planes_bf3.hip"]
 
 
 def build_all(force: bool = False, verbose: bool = True, variants=("", "f16")) -> list:

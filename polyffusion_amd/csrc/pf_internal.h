@@ -74,12 +74,6 @@ int launch_mlp_fused(const float* x, int batch, int l, const float* gamma, const
                      const void* w2, const float* b2, float* out, void* out_planes, hipStream_t stream, const void* w3 = nullptr,
                      const float* b3 = nullptr, const float* res3 = nullptr, float* stats3 = nullptr);
 
-// y = proj_in(GroupNorm(x)), q|k|v planes = qkv(LayerNorm1(y)) for C = 256 as one launch (preattn_fused_bf3.hip); w_in / w_qkv = bf16x3 packings.
-// gn_stats != nullptr: the GroupNorm finalize (producer tile statistics -> sc / sh rows) is folded into the launch as well.
-int launch_preattn_fused(const float* x, int batch, int l, float* sc, float* sh, const float* gn_stats, int gn_tiles, const float* gn_gamma,
-                         const float* gn_beta, float gn_eps, const void* w_in, const float* b_in, float* y, const float* ln_gamma,
-                         const float* ln_beta, float ln_eps, const void* w_qkv, void* qkv_planes, hipStream_t stream);
-
 size_t gn_scratch_bytes(int batch, int c, int hw);
 int launch_gn_scale_shift(const float* x0, int c0, const float* x1, int c1, int batch, int hw, int groups, float eps,
                           const float* gamma, const float* beta, float* scale, float* shift, void* scratch,

@@ -71,7 +71,7 @@ struct pf_unet {
   size_t cross_o_cursor = 0;
   const float* wdev = nullptr;
   void* amax_slot = nullptr;    // pf_unet_track_absmax: caller-owned device word, nullptr = off
-  int opt[PF_OPT_COUNT] = {PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO};   // pf_unet_set_option
+  int opt[PF_OPT_COUNT] = {PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO, PF_OPT_AUTO};   // pf_unet_set_option
   // profiling
   int precision = PF_PREC_F32;
   bool profiling = false;
@@ -592,16 +592,6 @@ static bool mlp_fused_wanted(int C, int hw, int M, int force) {
   return tiles * 100 >= 85 * cus * rounds;
 }
 
-// The fused pre-attention launch (preattn_fused_bf3.hip) has the feed-forward launch's shape - one four-wave workgroup per 64 tokens, a whole
-// CU each.  Measured (profiles/r05_ab_pre_fused.md): 44 us per launch back to back at L = 1024, B = 16 against ~60 us for the three launches
-// it replaces inside the step, but end to end between -2 % and +0.7 % depending on the box (on one the part clocked 4 % lower with it in
-// the plan) - so AUTO keeps the three launches; pf_unet_set_option(PF_OPT_PRE_FUSED, PF_OPT_ON) turns it on (d_model 256, L % 64 == 0).
-static bool preattn_fused_wanted(int C, int hw, int M, int force) {
-  (void)M;
-  if (C != 256 || hw % 64 != 0) return false;
-  return force == PF_OPT_ON;
-}
-
 static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const float* cond, const float* cross_all) {
   const int B = c.B, hw = H * W_, C = L.cin, M = B * hw, nh = c.u->cfg.n_heads, dh = C / nh, dc = c.u->cfg.d_cond;
   const float* x = xin.d;
@@ -618,17 +608,7 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
   const Ctx::GnRef gin = c.gn(xin, Tn{}, hw, 1e-6f, L.norm_g, L.norm_b, sc, sh, true);
   // bf16x3 mode, d_head 64, L % 128 == 0: every linear layer of the block runs on pre-split hi/lo planes (see the loop below)
   const bool planes_ok = c.u->precision == PF_PREC_BF16X3 && dh == 64 && hw % 128 == 0 && C % 32 == 0 && C <= 1024;
-  // ... and for d_model 256 the whole pre-attention half of the first layer - this GroupNorm, proj_in, LayerNorm1, q|k|v - is one launch
-  const bool pre_fused = planes_ok && !L.tbs.empty() && preattn_fused_wanted(C, hw, M, c.u->opt[PF_OPT_PRE_FUSED]) && !c.u->amax_slot;   // (range telemetry runs the chains: their epilogues carry it)
-  if (pre_fused) {
-    const Layer::TB& t = L.tbs[0];
-    c.prof_begin(PF_K_GEMM, 2.0 * M * ((double)C * C + 3.0 * C * C));
-    if (!c.dry && c.rc == PF_OK)
-      c.rc = launch_preattn_fused(x, B, hw, sc, sh, gin.fused ? gin.s0 : nullptr, gin.t0, gin.fused ? c.w(gin.g) : nullptr,
-                                  gin.fused ? c.w(gin.b) : nullptr, gin.eps, c.w(L.pin_w) + (size_t)C * C, c.w(L.pin_b), ta, c.w(t.n1g), c.w(t.n1b),
-                                  1e-5f, c.w(t.qkv) + (size_t)C * 3 * C, qkv, c.s);
-    c.prof_end();
-  } else {
+  {
     pf_conv_args a = conv_base(x, C, nullptr, 0, B, 1, hw, 1, c.w(L.pin_w), C, ta);
     a.prologue = 2; a.sc = sc; a.sh = sh; a.bias = c.w(L.pin_b);
     c.gn_attach(a, gin);
@@ -643,9 +623,7 @@ static Tn run_st(Ctx& c, const Layer& L, const Tn& xin, int H, int W_, const flo
     // global->LDS): LayerNorm is applied once per row into hi/lo planes instead of once per column tile in a GEMM prologue,
     // the projection writes pre-split q/k/v^T planes and attention runs on the bf16 pipe
     const bool planes = planes_ok;
-    if (pre_fused && i == 0) {
-      // q|k|v planes already written by the fused pre-attention launch above
-    } else if (planes) {
+    if (planes) {
       c.lnp(t0, M, C, t.n1g, t.n1b, att);   // `att` is free until attention writes it
       pf_conv_args a = conv_base(att, C, nullptr, 0, B, 1, hw, 1, c.w(t.qkv), 3 * C, qkv);
       a.a_planes = 1;
@@ -1186,12 +1164,6 @@ int pf_mlp_geglu_fused(const float* x, int batch, int l, const float* ln_gamma, 
                        const void* w1_bf16x3, const float* b1, const void* w2_bf16x3, const float* b2,
                        float* out, void* out_planes, void* stream) {
   return launch_mlp_fused(x, batch, l, ln_gamma, ln_beta, ln_eps, w1_bf16x3, b1, w2_bf16x3, b2, out, out_planes, (hipStream_t)stream);
-}
-int pf_preattn_fused(const float* x, int batch, int l, float* sc, float* sh, const float* gn_stats, int gn_tiles, const float* gn_gamma,
-                     const float* gn_beta, float gn_eps, const void* w_in_bf16x3, const float* b_in, float* y, const float* ln_gamma,
-                     const float* ln_beta, float ln_eps, const void* w_qkv_bf16x3, void* qkv_planes, void* stream) {
-  return launch_preattn_fused(x, batch, l, sc, sh, gn_stats, gn_tiles, gn_gamma, gn_beta, gn_eps, w_in_bf16x3, b_in, y, ln_gamma, ln_beta, ln_eps,
-                              w_qkv_bf16x3, qkv_planes, (hipStream_t)stream);
 }
 int pf_mlp_geglu_proj_fused(const float* x, int batch, int l, const float* ln_gamma, const float* ln_beta, float ln_eps,
                             const void* w1_bf16x3, const float* b1, const void* w2_bf16x3, const float* b2,

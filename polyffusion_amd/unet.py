@@ -244,7 +244,7 @@ class UNetModel:
         return ["f32", self._split_name][self._lib.pf_unet_get_precision(self._h)]
 
     # ---- plan options (which of two equivalent kernel forms the plan launches; include/pfhip.h PF_OPT_*) --------
-    _OPTS = {"mlp_fused": _lib.OPT_MLP_FUSED, "attn_wide": _lib.OPT_ATTN_WIDE, "conv_t16": _lib.OPT_CONV_T16, "conv_pp": _lib.OPT_CONV_PP, "pre_fused": _lib.OPT_PRE_FUSED, "conv_wino": _lib.OPT_CONV_WINO}
+    _OPTS = {"mlp_fused": _lib.OPT_MLP_FUSED, "attn_wide": _lib.OPT_ATTN_WIDE, "conv_t16": _lib.OPT_CONV_T16, "conv_pp": _lib.OPT_CONV_PP, "conv_wino": _lib.OPT_CONV_WINO}
 
     def set_option(self, name: str, value: Optional[bool]):
         """``None`` = automatic (the default), ``False`` / ``True`` = never / always (where the form exists)."""

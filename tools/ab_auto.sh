@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of one plan option, OFF against AUTO (the plan's own choice): bash tools/ab_auto.sh pre_fused [reps]  -> gpurun_out/ab/abauto_<option>.txt
+# same-box A/B of one plan option, OFF against AUTO (the plan's own choice): bash tools/ab_auto.sh conv_wino [reps]  -> gpurun_out/ab/abauto_<option>.txt
 opt=$1; reps=${2:-3}
 mkdir -p gpurun_out/ab
 F="--steps 50 --warmup 5 --no-cpu-baseline --profile-steps 0 --small-batch-steps 0 --fp32-steps 0 --f16x3-steps 0"

@@ -26,7 +26,7 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SOURCES = ["conv_bf16x3.hip", "gemm_planes_bf3.hip", "attention_bf3.hip", "mlp_fused_bf3.hip", "preattn_fused_bf3.hip"]
+SOURCES = ["conv_bf16x3.hip", "gemm_planes_bf3.hip", "attention_bf3.hip", "mlp_fused_bf3.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 sys.path.insert(0, REPO)
 from polyffusion_amd.build import EXTRA_FLAGS, VARIANTS  # noqa: E402  (the lint must read the assembly the library is built from)
