@@ -75,7 +75,7 @@ __device__ __forceinline__ const float* sbias_row_scalar(const ConvP& p, int b) 
   return p.sbias + (size_t)r * p.ld_sbias;
 }
 
-// ---- output transform + epilogue (shared by the kernel forms).  acc[j][h][nb]: this wave's row of the transform domain.
+// ---- output transform + epilogue.  acc[j][h][nb]: this wave's row of the transform domain.
 __device__ __forceinline__ void wino_epilogue(const ConvP& p, f32x16 (&acc)[4][2][2], unsigned char* smem_all, int b, int oy0, int ox0, int n0,
                                               int ty_t, int tx_t, int wave, int lane, int tid, const float* sb, bool trace_on = false, int tbase = 0, int tslot = 0) {
   (void)trace_on; (void)tbase; (void)tslot;
@@ -170,138 +170,6 @@ __device__ __forceinline__ void wino_epilogue(const ConvP& p, f32x16 (&acc)[4][2
     }
   }
   WTR();
-}
-
-template <int DUMMY>
-__global__ __launch_bounds__(256, 1) void conv_wino_kernel(ConvP p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-  float* H0 = reinterpret_cast<float*>(smem_all);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = row i of the transform domain
-
-  int lid;
-  {
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
-  int mt = fdiv(lid, p.d_nt);
-  const int nti = lid - mt * p.nt;
-  int t = fdiv(mt, p.d_tx);
-  const int tx_t = mt - t * p.tiles_x; mt = t;
-  const int b = fdiv(mt, p.d_ty);
-  const int ty_t = mt - b * p.tiles_y;
-  const int n0 = nti * 64, oy0 = ty_t * 16, ox0 = tx_t * 16;
-  conv_shared_x1(p, b);
-  const int cin = p.c0 + p.c1, nchunk = cin / 32, KK = cin / 16;
-
-  if (p.gn_s0) gn_fused_prologue<256>(p, b, tid, p.Hin * p.Win, reinterpret_cast<double*>(smem_all));
-
-  // ---- halo staging: piece = (pixel, 4-channel group); a thread keeps one channel group (256 % 8 == 0) and 11 pixels
-  const int sub = tid & 7;
-  int goff[11], loff[11];
-#pragma unroll
-  for (int it = 0; it < 11; ++it) {
-    const int pix = (tid >> 3) + 32 * it;
-    const int row = pix / 18, col = pix - row * 18;
-    const int iy = oy0 - 1 + row, ix = ox0 - 1 + col;
-    const bool valid = pix < 324;
-    goff[it] = (valid && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) ? (b * p.Hin + iy) * p.Win + ix : -1;
-    loff[it] = valid ? row * WRP + col * WPP + ((sub ^ ((row >> 1) & 1)) << 2) : -1;
-  }
-  auto stage = [&](int chunk) {
-    const int cg = chunk * 32;
-    const float* src; int cs, co;
-    if (cg < p.c0) { src = p.x0; cs = p.c0; co = cg; } else { src = p.x1; cs = p.c1; co = cg - p.c0; }
-    const f32x4 vsc = *reinterpret_cast<const f32x4*>(p.sc + (size_t)b * cin + cg + sub * 4);
-    const f32x4 vsh = *reinterpret_cast<const f32x4*>(p.sh + (size_t)b * cin + cg + sub * 4);
-    f32x4 ra[11];
-#pragma unroll
-    for (int it = 0; it < 11; ++it)
-      ra[it] = goff[it] >= 0 ? *reinterpret_cast<const f32x4*>(src + co + (size_t)goff[it] * cs + sub * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int it = 0; it < 11; ++it) {
-      f32x4 v = ra[it] * vsc + vsh;
-      v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
-      if (goff[it] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};     // zero padding applies to the ACTIVATED tensor
-      if (loff[it] >= 0) *reinterpret_cast<f32x4*>(H0 + loff[it]) = v;
-    }
-  };
-
-  // ---- A-operand side: lane = (tile m = lane & 31, channel group g = lane >> 5); B^T row of this wave: t = x + sigma * y
-  const int m = lane & 31, g = lane >> 5, tyl = m >> 3, txl = m & 7;
-  const int ax = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
-  const int ay = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
-  const float sigma = wave == 1 ? 1.f : -1.f;
-  // weights: [i][kk][ntile][j][nb][plane][lane][8]
-  const x3_t* wI = static_cast<const x3_t*>(p.w) + (size_t)wave * KK * p.nt * 8192 + (size_t)nti * 8192 + lane * 8;
-
-  f32x16 acc[4][2][2];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][h][nb][r] = 0.f;
-
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    __syncthreads();          // every wave has finished reading the previous image (and the GroupNorm scratch)
-    stage(chunk);
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const x3_t* wq = wI + (size_t)(chunk * 2 + s) * p.nt * 8192;
-      x3x8 bh[4][2], bl[4][2];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          bh[j][nb] = *reinterpret_cast<const x3x8*>(wq + ((j * 2 + nb) * 2 + 0) * 512);
-          bl[j][nb] = *reinterpret_cast<const x3x8*>(wq + ((j * 2 + nb) * 2 + 1) * 512);
-        }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int rx = 2 * (4 * h + tyl) + ax, ry = 2 * (4 * h + tyl) + ay;
-        const float* px = H0 + rx * WRP + (2 * txl) * WPP + s * 16;
-        const float* py = H0 + ry * WRP + (2 * txl) * WPP + s * 16;
-        const int sx = (rx >> 1) & 1, sy = (ry >> 1) & 1;
-        f32x4 tt[4][2];
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const f32x4 X = *reinterpret_cast<const f32x4*>(px + bb * WPP + (((2 * g + e) ^ sx) << 2));
-            const f32x4 Y = *reinterpret_cast<const f32x4*>(py + bb * WPP + (((2 * g + e) ^ sy) << 2));
-            tt[bb][e] = X + sigma * Y;
-          }
-        x3x8 ah[4], al[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          x3x4 hq[2], lq[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const f32x4 v = j == 0 ? tt[0][e] - tt[2][e] : (j == 1 ? tt[1][e] + tt[2][e] : (j == 2 ? tt[2][e] - tt[1][e] : tt[1][e] - tt[3][e]));
-            hq[e] = __builtin_convertvector(v, x3x4);
-            lq[e] = __builtin_convertvector(v - __builtin_convertvector(hq[e], f32x4), x3x4);
-          }
-          ah[j] = __builtin_shufflevector(hq[0], hq[1], 0, 1, 2, 3, 4, 5, 6, 7);
-          al[j] = __builtin_shufflevector(lq[0], lq[1], 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            acc[j][h][nb] = x3_mfma_32x32x16(al[j], bh[j][nb], acc[j][h][nb], 0, 0, 0);
-            acc[j][h][nb] = x3_mfma_32x32x16(ah[j], bl[j][nb], acc[j][h][nb], 0, 0, 0);
-            acc[j][h][nb] = x3_mfma_32x32x16(ah[j], bh[j][nb], acc[j][h][nb], 0, 0, 0);
-          }
-      }
-    }
-  }
-
-  wino_epilogue(p, acc, smem_all, b, oy0, ox0, n0, ty_t, tx_t, wave, lane, tid, sbias_row(p, b));
 }
 
 // x * sigmoid(x) on a pair: the multiplies and the add as packed operations (two elements per instruction), one v_exp + one v_rcp per element
@@ -684,17 +552,10 @@ int launch_conv_wino(const pf_conv_args& a, hipStream_t stream) {
   p.tiles_x = a.win / 16; p.tiles_y = a.hin / 16; p.nt = a.n / 64;
   conv_fill_divs(p);
   const int grid = p.B * p.tiles_y * p.tiles_x * p.nt;
-  if (a.wino == 2) {          // the plain (un-pipelined) form: development reference
-    auto kern = conv_wino_kernel<0>;
-    static std::atomic<uint64_t> attr_done{0};
-    if (int rc = set_max_lds_once(reinterpret_cast<const void*>(kern), WINO_LDS, attr_done)) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), WINO_LDS, stream, p);
-  } else {
-    auto kern = conv_wino_pipe_kernel<0>;
-    static std::atomic<uint64_t> attr_done{0};
-    if (int rc = set_max_lds_once(reinterpret_cast<const void*>(kern), WINO_LDS, attr_done)) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), WINO_LDS, stream, p);
-  }
+  auto kern = conv_wino_pipe_kernel<0>;
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = set_max_lds_once(reinterpret_cast<const void*>(kern), WINO_LDS, attr_done)) return rc;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), WINO_LDS, stream, p);
   PF_CHECK_HIP(hipGetLastError());
   return PF_OK;
 }
