@@ -141,7 +141,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
   // Fragment registers, double-buffered per SLOT: while the MFMAs of slot i run on one set, every fragment of slot i+1 is read into
   // the other (a 16-byte LDS read needs 100-200 cycles to come back; with the per-K-step skew of gemm_planes_bf3.hip this
   // tile's two-MFMA groups gave a read 64-128 cycles of cover and the wave spent more time waiting than multiplying).
-  x3x8 fal[2][2], fah[2][2], fbh[2][2][2], fbl[2][2][2];   // ff1 slot: [set][K step]([fn])
+  x3x8 fbh[2][2][2], fbl[2][2][2];                          // ff1 slot, weights: [set][K step][fn]
+  // The A operand of ff1 - this wave's 32 rows of the LayerNorm planes, all 256 channels - is RESIDENT in registers (8 chunks x 2 K steps x
+  // hi | lo = 128 registers; one wave per SIMD has 512): read from the LDS once instead of once per slice.  With them in the LDS an ff1
+  // slot read 12 fragments for its 12 MFMAs - 48 KB per slot for the four waves, the LDS port busy for as long as the matrix pipe; a timing
+  // variant without those reads ran 90 -> 78 us.
+  x3x8 Al[8][2], Ah[8][2];
   x3x8 gal[2], gah[2], gbh[2][4], gbl[2][4];                // ff2 slot: [set]([fn])
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define IC(N) std::integral_constant<int, (N)>{}
@@ -149,13 +154,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
 #define FROM_A std::true_type{}
 #define OPEN_B std::true_type{}
 #define OPEN_A std::false_type{}
-  // n-th fragment read (in consumption order: al, bh0, bh1, ah, bl0, bl1 per K step) of ff1 slot (chunk CC, ring position RP) into set S
-  auto ld1 = [&](auto S_, auto CC_, auto RP_, auto N_) {
-    constexpr int S = S_.value, CC = CC_.value, RP = RP_.value, ks = N_.value / 6, m = N_.value % 6;
-    if constexpr (m == 0) fal[S][ks] = lds_read128<CC * CH_B + LO_B>(ks ? ab1 : ab0);
-    else if constexpr (m <= 2) fbh[S][ks][m - 1] = lds_read128<RP * SLOT_B + ((4 * ks) * 128 + (m - 1) * 32) * 16>(wb1);
-    else if constexpr (m == 3) fah[S][ks] = lds_read128<CC * CH_B>(ks ? ab1 : ab0);
-    else fbl[S][ks][m - 4] = lds_read128<RP * SLOT_B + ((4 * ks + 1) * 128 + (m - 4) * 32) * 16>(wb1);
+  // n-th weight fragment read (in consumption order: bh0, bh1, bl0, bl1 per K step) of an ff1 slot at ring position RP into set S
+  auto ld1 = [&](auto S_, auto RP_, auto N_) {
+    constexpr int S = S_.value, RP = RP_.value, ks = N_.value / 4, m = N_.value % 4;
+    if constexpr (m < 2) fbh[S][ks][m] = lds_read128<RP * SLOT_B + ((4 * ks) * 128 + m * 32) * 16>(wb1);
+    else fbl[S][ks][m - 2] = lds_read128<RP * SLOT_B + ((4 * ks + 1) * 128 + (m - 2) * 32) * 16>(wb1);
   };
   // ff2 slot (16-deep step CC of the slice, ring position RP): n = 0..3 bh, 4..7 bl (weights), 8 al, 9 ah (the GeGLU product in sH)
   auto ld2 = [&](auto S_, auto CC_, auto RP_, auto N_, auto FROMA_) {
@@ -167,11 +170,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
     else gah[S] = lds_read128<(CC >> 1) * CH_B>(fa ? ((CC & 1) ? ab1 : ab0) : ((CC & 1) ? hb1 : hb0));
   };
   // n-th MFMA of a slot: per K step X X Z Z Y Y (ff1, two column fragments) / X X X X Z Z Z Z Y Y Y Y (ff2, four)
-  auto mf1 = [&](auto S_, auto N_) {
-    constexpr int S = S_.value, ks = N_.value / 6, m = N_.value % 6, fn = m & 1;
-    if constexpr (m < 2) acc1[fn] = x3_mfma_32x32x16(fal[S][ks], fbh[S][ks][fn], acc1[fn], 0, 0, 0);
-    else if constexpr (m < 4) acc1[fn] = x3_mfma_32x32x16(fah[S][ks], fbh[S][ks][fn], acc1[fn], 0, 0, 0);
-    else acc1[fn] = x3_mfma_32x32x16(fah[S][ks], fbl[S][ks][fn], acc1[fn], 0, 0, 0);
+  auto mf1 = [&](auto S_, auto CC_, auto N_) {
+    constexpr int S = S_.value, CC = CC_.value, ks = N_.value / 6, m = N_.value % 6, fn = m & 1;
+    if constexpr (m < 2) acc1[fn] = x3_mfma_32x32x16(Al[CC][ks], fbh[S][ks][fn], acc1[fn], 0, 0, 0);
+    else if constexpr (m < 4) acc1[fn] = x3_mfma_32x32x16(Ah[CC][ks], fbh[S][ks][fn], acc1[fn], 0, 0, 0);
+    else acc1[fn] = x3_mfma_32x32x16(Ah[CC][ks], fbl[S][ks][fn], acc1[fn], 0, 0, 0);
   };
   auto mf2 = [&](auto S_, auto N_) {
     constexpr int S = S_.value, g = N_.value / 4, fn = N_.value % 4;
@@ -267,12 +270,12 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
     FRAGS_READY();
     static_for<0, 12>([&](auto nn) {
       constexpr int n = nn.value, m = n - 2;   // m: index among the gaps that carry the next slot's fragment reads
-      mf1(IC(S), nn); SB();
+      mf1(IC(S), cc, nn); SB();
       if constexpr (n == 1) SLOT_SYNC();
       if constexpr (m >= 0 && m < 4) {
-        if constexpr (next.value == 0) { ld1(IC(NS), IC(c + 1), IC(rpn), IC(3 * m)); ld1(IC(NS), IC(c + 1), IC(rpn), IC(3 * m + 1)); ld1(IC(NS), IC(c + 1), IC(rpn), IC(3 * m + 2)); }
+        if constexpr (next.value == 0) { ld1(IC(NS), IC(rpn), IC(2 * m)); ld1(IC(NS), IC(rpn), IC(2 * m + 1)); }
         else if constexpr (next.value == 1) { ld2(IC(0), IC(0), IC(rpn), IC(2 * m), FROM_H); ld2(IC(0), IC(0), IC(rpn), IC(2 * m + 1), FROM_H); }
-        else { ld1(IC(NS), IC(0), IC(rpn), IC(3 * m)); ld1(IC(NS), IC(0), IC(rpn), IC(3 * m + 1)); ld1(IC(NS), IC(0), IC(rpn), IC(3 * m + 2)); }
+        else { ld1(IC(NS), IC(rpn), IC(2 * m)); ld1(IC(NS), IC(rpn), IC(2 * m + 1)); }
       }
       if constexpr (n >= 2 && n < 6) dma(cc, IC(n - 2));
       if constexpr (fill.value && c * 12 + n < NPIECE) geglu_piece(IC(c * 12 + n));
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
       if constexpr (n == 1 && c != 0) SLOT_SYNC();
       if constexpr (m >= 0) {
         if constexpr (next.value == 0) { if constexpr (m < 5) { ld2(IC(NS), IC(c + 1), IC(rpn), IC(2 * m), froma); ld2(IC(NS), IC(c + 1), IC(rpn), IC(2 * m + 1), froma); } }
-        else if constexpr (next.value == 1) { if constexpr (m < 4) { ld1(IC(NS), IC(0), IC(rpn), IC(3 * m)); ld1(IC(NS), IC(0), IC(rpn), IC(3 * m + 1)); ld1(IC(NS), IC(0), IC(rpn), IC(3 * m + 2)); } }
+        else if constexpr (next.value == 1) { if constexpr (m < 4) { ld1(IC(NS), IC(rpn), IC(2 * m)); ld1(IC(NS), IC(rpn), IC(2 * m + 1)); } }
         else if constexpr (next.value == 2) { if constexpr (m < 4) { ld2(IC(NS), IC(0), IC(rpn), IC(2 * m), FROM_H); ld2(IC(NS), IC(0), IC(rpn), IC(2 * m + 1), FROM_H); } }
       }
       if constexpr (n >= 2 && n < 6) dma(cc, IC(n - 2));
@@ -328,7 +331,11 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 2) * 4) : "memory");   // slot P0 landed, LN planes and bias written
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  static_for<0, 12>([&](auto n) { ld1(IC(0), IC(0), IC(0), n); });
+  static_for<0, 8>([&](auto n) { ld1(IC(0), IC(0), n); });
+  static_for<0, 8>([&](auto c) {          // the resident A operand
+    Al[c.value][0] = lds_read128<c.value * CH_B + LO_B>(ab0); Al[c.value][1] = lds_read128<c.value * CH_B + LO_B>(ab1);
+    Ah[c.value][0] = lds_read128<c.value * CH_B>(ab0); Ah[c.value][1] = lds_read128<c.value * CH_B>(ab1);
+  });
   load_bias(0);
   SB();
 #pragma unroll
@@ -387,7 +394,6 @@ __global__ __launch_bounds__(256, 1) void mlp_bf3_kernel(ConvP p, MlpX e) {
   // the fragment reads of an ff1 slice that never runs are dead values to the compiler: keep their registers until the wait above
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    asm volatile("" ::"v"(fal[0][k]), "v"(fah[0][k]));
 #pragma unroll
     for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(fbh[0][k][i]), "v"(fbl[0][k][i]));
   }
